@@ -1,0 +1,132 @@
+"""Seeded synthetic inputs (volumes, U-Net / ICON weights, displacement fields).
+
+There are no network assets in this environment (the reference downloads its
+knee, atlas and weights with pooch, oai_analysis/data.py:8-22), so parity tests and
+``bench.py`` run on seeded synthetic data of the reference's shapes.
+Everything is generated with the torch *CPU* generator so that the container that
+makes the golden fixtures and the GPU box produce bit-identical inputs.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# (name, kind, cin, cout) in reference order, networks.py:43-66.  Weight shapes:
+#   'c3' Conv3d            [cout, cin, 3,3,3]      'c1' Conv3d [cout, cin, 1,1,1]
+#   't3' ConvTranspose3d   [cin, cout, 3,3,3]      'up' ConvTranspose3d [cin, cout, 2,2,2]
+UNET_SPEC = [
+    ("ec0", "c3", 1, 32), ("ec1", "c3", 32, 64), ("ec2", "c3", 64, 64), ("ec3", "c3", 64, 128),
+    ("ec4", "c3", 128, 128), ("ec5", "c3", 128, 256), ("ec6", "c3", 256, 256), ("ec7", "c3", 256, 512),
+    ("dc9", "up", 512, 512), ("dc8", "t3", 768, 256), ("dc7", "t3", 256, 256),
+    ("dc6", "up", 256, 256), ("dc5", "t3", 384, 128), ("dc4", "t3", 128, 128),
+    ("dc3", "up", 128, 128), ("dc2", "t3", 192, 64), ("dc1", "t3", 64, 64),
+]
+
+
+def make_unet_state_dict(seed: int = 0, n_classes: int = 2, in_channels: int = 1, bias: bool = True,
+                         bn: bool = False, width_div: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    """State dict with the reference ``UNet`` key names.
+
+    He-scaled normal weights keep activations O(1) through the 18 ReLU layers so that the
+    logits straddle 0 and the thresholded masks are a meaningful parity target.
+    ``width_div`` shrinks every hidden width (tests of the generic kernels only; the
+    reference network is ``width_div=1``).
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def ch(c):
+        return max(1, c // width_div)
+
+    for name, kind, cin, cout in UNET_SPEC:
+        cin_e = in_channels if name == "ec0" else ch(cin)
+        cout_e = ch(cout)
+        k = {"c3": 3, "t3": 3, "up": 2}[kind]
+        shape = (cout_e, cin_e, k, k, k) if kind == "c3" else (cin_e, cout_e, k, k, k)
+        taps = 27 if k == 3 else 1        # a k2s2 up-conv has one tap per output voxel
+        std = math.sqrt(2.0 / (cin_e * taps))
+        sd[f"{name}.0.weight"] = torch.randn(shape, generator=g) * std
+        if bias:
+            sd[f"{name}.0.bias"] = (torch.rand(cout_e, generator=g) - 0.5) * 0.1
+        if bn:
+            sd[f"{name}.1.weight"] = 0.5 + torch.rand(cout_e, generator=g)
+            sd[f"{name}.1.bias"] = (torch.rand(cout_e, generator=g) - 0.5) * 0.2
+            sd[f"{name}.1.running_mean"] = (torch.rand(cout_e, generator=g) - 0.5) * 0.2
+            sd[f"{name}.1.running_var"] = 0.5 + torch.rand(cout_e, generator=g)
+            sd[f"{name}.1.num_batches_tracked"] = torch.tensor(1000, dtype=torch.long)
+    c_last = ch(64)
+    sd["dc0.weight"] = torch.randn((n_classes, c_last, 1, 1, 1), generator=g) * math.sqrt(1.0 / c_last)
+    if bias:
+        sd["dc0.bias"] = (torch.rand(n_classes, generator=g) - 0.5) * 0.1
+    return sd
+
+
+def make_volume(seed: int, shape_zyx: Sequence[int] = (160, 384, 384)) -> np.ndarray:
+    """Knee-like volume in [0,1]: smooth low-frequency field + 0.05*N(0,1) noise, clamped."""
+    g = torch.Generator().manual_seed(1234 + seed)
+    coarse = [max(2, int(math.ceil(s / 8))) for s in shape_zyx]
+    low = torch.rand((1, 1, *coarse), generator=g)
+    smooth = F.interpolate(low, size=tuple(shape_zyx), mode="trilinear", align_corners=True)[0, 0]
+    noise = torch.randn(tuple(shape_zyx), generator=g) * 0.05
+    return (smooth + noise).clamp_(0.0, 1.0).numpy().astype(np.float32)
+
+
+def make_smooth_field(seed: int, shape_zyx: Sequence[int], amplitude: float, coarse: int = 10) -> np.ndarray:
+    """Smooth 3-channel displacement field [3,D,H,W] in [0,1] map units."""
+    g = torch.Generator().manual_seed(4321 + seed)
+    low = torch.randn((1, 3, coarse, coarse, coarse), generator=g)
+    up = F.interpolate(low, size=tuple(shape_zyx), mode="trilinear", align_corners=True)[0]
+    return (up * amplitude).numpy().astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# ICON (icon_registration.networks.tallUNet2) synthetic weights
+
+ICON_DOWN = [2, 16, 32, 64, 256, 512]
+ICON_UP_OUT = [16, 32, 64, 128, 256]
+ICON_UP_IN = [48, 96, 192, 512, 512]      # down[1:] + (up_out[1:] + [0])
+
+
+def make_icon_unet_state_dict(seed: int, dimension: int = 3, last_scale: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+    """Weights of one ``tallUNet2`` with the public package's parameter names.
+
+    ``lastConv`` is zero-initialised in the real package and learnt; a trained net emits
+    displacements of a few percent of the image extent, which ``last_scale`` reproduces.
+    """
+    g = torch.Generator().manual_seed(7000 + seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for d in range(5):
+        cin, cout = ICON_DOWN[d], ICON_DOWN[d + 1]
+        sd[f"downConvs.{d}.weight"] = torch.randn((cout, cin, 3, 3, 3), generator=g) * math.sqrt(1.0 / (cin * 27))
+        sd[f"downConvs.{d}.bias"] = (torch.rand(cout, generator=g) - 0.5) * 0.1
+        cin, cout = ICON_UP_IN[d], ICON_UP_OUT[d]
+        # a k4 s2 p1 transposed conv touches 8 of its 64 taps per output voxel
+        sd[f"upConvs.{d}.weight"] = torch.randn((cin, cout, 4, 4, 4), generator=g) * math.sqrt(1.0 / (cin * 8))
+        sd[f"upConvs.{d}.bias"] = (torch.rand(cout, generator=g) - 0.5) * 0.1
+        sd[f"batchNorms.{d}.weight"] = 0.75 + 0.5 * torch.rand(cout, generator=g)
+        sd[f"batchNorms.{d}.bias"] = (torch.rand(cout, generator=g) - 0.5) * 0.2
+        sd[f"batchNorms.{d}.running_mean"] = (torch.rand(cout, generator=g) - 0.5) * 0.2
+        sd[f"batchNorms.{d}.running_var"] = 0.75 + 0.5 * torch.rand(cout, generator=g)
+        sd[f"batchNorms.{d}.num_batches_tracked"] = torch.tensor(1000, dtype=torch.long)
+    sd["lastConv.weight"] = torch.randn((3, 18, 3, 3, 3), generator=g) * (last_scale * math.sqrt(1.0 / (18 * 27)))
+    sd["lastConv.bias"] = (torch.rand(3, generator=g) - 0.5) * 0.02 * last_scale
+    return sd
+
+
+def make_icon_state_dict(seed: int = 0, last_scale: float = 0.3) -> "OrderedDict[str, torch.Tensor]":
+    """``regis_net`` state dict of ``OAI_knees_gradICON_model``: three tallUNet2s.
+
+    Key prefixes follow the module tree TwoStep(Downsample(TwoStep(FFVF,FFVF)),FFVF):
+    ``netPhi.net.netPhi.net.*`` (u1, low-res), ``netPhi.net.netPsi.net.*`` (u2, low-res),
+    ``netPsi.net.*`` (u3, full-res).
+    """
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for i, prefix in enumerate(("netPhi.net.netPhi.net.", "netPhi.net.netPsi.net.", "netPsi.net.")):
+        for k, v in make_icon_unet_state_dict(seed * 3 + i, last_scale=last_scale).items():
+            out[prefix + k] = v
+    return out
