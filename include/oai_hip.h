@@ -1,0 +1,179 @@
+/* liboai_hip.so -- C ABI of the MI355X (gfx950) hot path of OAI_analysis_2.
+ *
+ * The reference (uncbiag/OAI_analysis_2 @ 2024_10_08) has no FFI of its own: its seam is
+ * Python duck typing.  The entry points below are what a binding for that seam
+ * calls; each one names the reference interface it stands in for.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; oai_last_error() gives the text
+ *     (thread-local).  Nothing aborts, nothing throws across the boundary.
+ *   - every pointer named *_dev is device memory owned by the caller (e.g. a PyTorch-ROCm
+ *     tensor's data_ptr()); host pointers are named *_host.  No torch types cross the boundary.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Launch functions
+ *     enqueue work and return; they never synchronise, allocate or free (graph-capturable).
+ *   - volumes are [z][y][x] (numpy / torch order), fp32 unless stated.  Vector fields and
+ *     coordinate maps are channel-first [3][D][H][W], channel c along tensor axis c (z,y,x),
+ *     in ICON's normalised [0,1] units (index / (n-1)).
+ *   - a handle is not thread-safe; distinct handles are.
+ */
+#ifndef OAI_HIP_H
+#define OAI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OAI_OK 0
+#define OAI_ERR_ARG 1
+#define OAI_ERR_HIP 2
+#define OAI_ERR_WORKSPACE 3
+
+int oai_version(void);
+const char* oai_last_error(void);
+/* Fills name (<= cap bytes) with the device's gcnArchName; returns the CU count or -1. */
+int oai_device_info(char* name, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Registration warp family.  Replaces torch.nn.functional.grid_sample / avg_pool3d /
+ * interpolate as reached from oai_analysis/registration.py:25 (icon_registration.itk_wrapper.
+ * register_pair -> network_wrappers / mermaidlite.compute_warped_image_multiNC), and the ITK
+ * resample of test/test_all.py:42-52 / oai_analysis/dask_processing.py:95-111.
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[c][D][H][W] = trilinear sample of src[c][d][h][w] at coords (ICON [0,1] units; border
+ * clamp, align_corners=True).  coords_dev == NULL means the identity map of [D][H][W].
+ * = mermaidlite.compute_warped_image_multiNC(src, coords, spacing, 1). */
+int oai_grid_sample3d(const float* src_dev, int C, int d, int h, int w,
+                      const float* coords_dev, int D, int H, int W, float* out_dev, void* stream);
+
+/* out = coords + sample(disp, coords): FunctionFromVectorField's transform(coords).
+ * coords_dev == NULL means the identity map (the "sampled" path at another resolution);
+ * if additionally (d,h,w)==(D,H,W) and shortcut != 0, out = identity + disp exactly
+ * (the package's isIdentity shortcut, no interpolation). */
+int oai_compose(const float* disp_dev, int d, int h, int w, const float* coords_dev,
+                int D, int H, int W, int shortcut, float* out_dev, void* stream);
+
+/* F.avg_pool3d(x, 2, ceil_mode=True) on [C][D][H][W] -> [C][ceil(D/2)][ceil(H/2)][ceil(W/2)]. */
+int oai_avgpool2_3d(const float* in_dev, int C, int D, int H, int W, float* out_dev, void* stream);
+
+/* F.interpolate(x, size=(D,H,W), mode="trilinear", align_corners=False) on [C][d][h][w]. */
+int oai_resize_trilinear(const float* in_dev, int C, int d, int h, int w,
+                         float* out_dev, int D, int H, int W, void* stream);
+
+/* itk_wrapper.create_itk_transform's vector image: disp[z][y][x][3] (float64, components x,y,z,
+ * network-voxel units) = reverse_components((phi - identity) * (shape - 1)). */
+int oai_phi_to_itk_displacement(const float* phi_dev, int D, int H, int W, double* disp_dev, void* stream);
+
+/* Geometry of one image for the resample: index_xyz -> physical = A*idx + b (row-major 3x3 + 3). */
+typedef struct oai_affine { double A[9]; double b[3]; } oai_affine;
+
+/* warped[zB][yB][xB] = prob_A(phi_AB(p)): ITK ResampleImageFilter(prob, transform=phi_AB,
+ * LinearInterpolateImageFunction, reference grid = image_B, default pixel 0), with phi_AB the
+ * CompositeTransform [to_network_space, DisplacementFieldTransform, from_network_space].
+ *   b_index_to_net : B index  -> network index space   (T_B^-1 o index_to_physical_B)
+ *   net_to_a_index : network index space -> A continuous index (physical_to_index_A o T_A)
+ *   disp_dev       : float64 [Dn][Hn][Wn][3] from oai_phi_to_itk_displacement. */
+int oai_resample_through_disp(const float* prob_dev, int nzA, int nyA, int nxA,
+                              const double* disp_dev, int Dn, int Hn, int Wn,
+                              const oai_affine* b_index_to_net, const oai_affine* net_to_a_index,
+                              float* out_dev, int nzB, int nyB, int nxB, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Segmentation.  Replaces `self.model(temp_input.to(self.device)).cpu()` and the code around
+ * it in Segmenter3DInPatchClassWise.segment (oai_analysis/segmentation/segmenter.py:100-131):
+ * Partition.__call__ (image_transforms.py:395-455), UNet.forward (networks.py:109-149),
+ * torch.sigmoid / >0.5 (segmenter.py:121-124) and Partition.assemble (image_transforms.py:457-519).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct oai_unet oai_unet;
+
+/* One conv block in the reference's own tensor layouts (host memory, fp32):
+ *   kind 0: Conv3d k3 s1 p1           weight [Cout][Cin][3][3][3]
+ *   kind 1: ConvTranspose3d k3 s1 p1  weight [Cin][Cout][3][3][3]
+ *   kind 2: ConvTranspose3d k2 s2     weight [Cin][Cout][2][2][2]
+ *   kind 3: Conv3d k1                 weight [Cout][Cin]
+ * bias / bn_* may be NULL (bias=False / BN=False, networks.py:39). */
+typedef struct oai_layer_params {
+    int kind, cin, cout;
+    const float* weight_host;
+    const float* bias_host;
+    const float* bn_gamma_host;
+    const float* bn_beta_host;
+    const float* bn_mean_host;
+    const float* bn_var_host;
+} oai_layer_params;
+
+#define OAI_UNET_NUM_LAYERS 18 /* ec0..ec7, dc9, dc8, dc7, dc6, dc5, dc4, dc3, dc2, dc1, dc0 */
+
+/* Ingests a reference state_dict (strict, like utils.initialize_model, utils.py:29): packs
+ * the weights for the kernels (transposed-conv flip, K-permuted MFMA panels) and uploads them. */
+int oai_unet_create(const oai_layer_params layers_host[OAI_UNET_NUM_LAYERS], float bn_eps, oai_unet** out);
+void oai_unet_destroy(oai_unet* h);
+
+/* Bytes of device scratch oai_unet_forward_* needs for `batch` tiles of (td,th,tw). */
+size_t oai_unet_workspace_bytes(const oai_unet* h, int td, int th, int tw, int batch);
+
+/* B3 seam: logits[B][n_classes][td][th][tw] = UNet(tiles[B][1][td][th][tw]) (NCDHW like
+ * networks.py:109-149), zero conv padding at the tile border, no trimming. */
+int oai_unet_forward_tiles(oai_unet* h, const float* tiles_dev, float* logits_dev, int B,
+                           int td, int th, int tw, void* workspace_dev, size_t workspace_bytes,
+                           void* stream);
+
+/* Fused a3-a7 of SURVEY.md 8a for tiles [tile_begin, tile_end) of the reference's z-major tile
+ * order: reflect-pad addressing of vol[D][H][W] (no tiles materialised) -> UNet on each tile ->
+ * 1x1x1 head -> sigmoid (out_mode 0) or sigmoid>0.5 as 0/1 (out_mode 1) or raw logits (2) ->
+ * kept centre blocks blocks_dev[tile - tile_begin][n_classes][ez][ey][ex] (e = tile - 2*overlap).
+ * Only the region each layer needs for the kept centre is computed (bit-identical trim). */
+int oai_segment_tiles(oai_unet* h, const float* vol_dev, int D, int H, int W,
+                      const int tile_zyx[3], const int overlap_zyx[3], int tile_begin, int tile_end,
+                      int out_mode, float* blocks_dev, int batch,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Partition.assemble (non-vote branch): scatter centre blocks of ALL tiles into
+ * maps[n_classes][D][H][W], trim to the image, zero the outer frame of crop_zyx voxels. */
+int oai_stitch_blocks(const float* blocks_dev, int n_classes, int D, int H, int W,
+                      const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
+                      float* maps_dev, void* stream);
+
+/* Algorithmic FLOPs (2*MACs) of one tile, full or with the dead-output trim. */
+double oai_unet_tile_flops(const oai_unet* h, int td, int th, int tw, const int overlap_zyx[3], int trimmed);
+
+/* ------------------------------------------------------------------------------------------
+ * ICON registration network.  Replaces icon_registration.pretrained_models.
+ * OAI_knees_gradICON_model (registration.py:20) + the network part of register_pair (:25).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct oai_icon oai_icon;
+
+/* One tallUNet2 = UNet2(5, [[2,16,32,64,256,512],[16,32,64,128,256]], 3) in the package's layouts
+ * (host, fp32): downConvs[d].weight [Co][Ci][3][3][3], upConvs[d].weight [Ci][Co][4][4][4],
+ * batchNorms[d].{weight,bias,running_mean,running_var}, lastConv.weight [3][18][3][3][3]. */
+typedef struct oai_icon_unet_params {
+    const float* down_w[5]; const float* down_b[5];
+    const float* up_w[5];   const float* up_b[5];
+    const float* bn_gamma[5]; const float* bn_beta[5]; const float* bn_mean[5]; const float* bn_var[5];
+    const float* last_w; const float* last_b;
+} oai_icon_unet_params;
+
+/* nets[0], nets[1]: the two low-resolution steps; nets[2]: the full-resolution step. */
+int oai_icon_create(const oai_icon_unet_params nets_host[3], int D, int H, int W, oai_icon** out);
+void oai_icon_destroy(oai_icon* h);
+size_t oai_icon_workspace_bytes(const oai_icon* h);
+
+/* phi_AB(identity)[3][D][H][W] for network-resolution images A, B [D][H][W] (one direction of
+ * GradientICON.forward followed by model.phi_AB(model.identity_map)). */
+int oai_icon_forward(oai_icon* h, const float* A_dev, const float* B_dev, float* phi_dev,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* One tallUNet2 forward on its own (unit-test seam): out[3][D][H][W] = net(a, b). */
+int oai_icon_unet_forward(oai_icon* h, int which, const float* a_dev, const float* b_dev, int D, int H, int W,
+                          float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OAI_HIP_H */

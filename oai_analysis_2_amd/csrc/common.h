@@ -1,0 +1,32 @@
+// Shared host-side helpers of liboai_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/oai_hip.h"
+
+namespace oai {
+
+char* error_buffer();                      // thread-local, 512 bytes
+int set_error(int code, const char* fmt, ...);
+
+#define OAI_CHECK_ARG(cond, ...)                                            \
+    do {                                                                    \
+        if (!(cond)) return ::oai::set_error(OAI_ERR_ARG, __VA_ARGS__);     \
+    } while (0)
+
+#define OAI_CHECK_HIP(expr)                                                               \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return ::oai::set_error(OAI_ERR_HIP, "%s failed: %s (%s:%d)", #expr,          \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);           \
+    } while (0)
+
+// after a kernel launch: catches bad launch configurations without synchronising
+#define OAI_CHECK_LAUNCH() OAI_CHECK_HIP(hipGetLastError())
+
+static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace oai

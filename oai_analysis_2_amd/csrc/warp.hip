@@ -1,0 +1,351 @@
+// HBM-bound registration kernels for gfx950: trilinear gather (grid_sample3d), displacement
+// compose, 2x average pool, trilinear resize, phi -> ITK displacement, and the fused
+// prob-map resample through phi.
+//
+// Reference semantics restated (see include/oai_hip.h for the call sites):
+//   torch.nn.functional.grid_sample(mode='bilinear', padding_mode='border', align_corners=True)
+//   behind icon_registration.mermaidlite.compute_warped_image_multiNC (scale_map: g = 2*c - 1,
+//   channel reversal to xyz).  One thread owns VEC consecutive x voxels: coordinate planes are
+//   read and results written with 16-byte accesses; the 8-tap gathers hit neighbouring lines
+//   because registration maps are near-identity.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float identity_coord(int i, double inv_nm1) {
+    // mermaidlite.identity_map: float32(index * spacing) with spacing = 1/(n-1) in float64
+    return (float)((double)i * inv_nm1);
+}
+
+// PyTorch grid_sampler_compute_source_index (align_corners=True) + border clip
+__device__ __forceinline__ float unnormalize_border(float c01, int size) {
+    float g = c01 * 2.0f - 1.0f;                       // scale_map
+    float ix = ((g + 1.0f) * 0.5f) * (float)(size - 1);
+    return fminf((float)(size - 1), fmaxf(ix, 0.0f));
+}
+
+struct Taps {
+    int o[8];      // linear offsets of the 8 corners inside one [d][h][w] plane, or -1
+    float w[8];
+};
+
+__device__ __forceinline__ void make_taps(float cz, float cy, float cx, int d, int h, int w, Taps& t) {
+    const float iz = unnormalize_border(cz, d), iy = unnormalize_border(cy, h), ix = unnormalize_border(cx, w);
+    const float fz0 = floorf(iz), fy0 = floorf(iy), fx0 = floorf(ix);
+    const int z0 = (int)fz0, y0 = (int)fy0, x0 = (int)fx0;
+    const float wz1 = iz - fz0, wy1 = iy - fy0, wx1 = ix - fx0;          // weight of the "+1" corner
+    const float wz0 = (fz0 + 1.0f) - iz, wy0 = (fy0 + 1.0f) - iy, wx0 = (fx0 + 1.0f) - ix;
+    const bool zin = z0 + 1 < d, yin = y0 + 1 < h, xin = x0 + 1 < w;     // the "+1" corner exists
+    const int base = (z0 * h + y0) * w + x0;
+    // PyTorch order: tnw tne tsw tse bnw bne bsw bse  (t/b = z, n/s = y, w/e = x)
+    t.o[0] = base;                         t.w[0] = wx0 * wy0 * wz0;
+    t.o[1] = xin ? base + 1 : -1;          t.w[1] = wx1 * wy0 * wz0;
+    t.o[2] = yin ? base + w : -1;          t.w[2] = wx0 * wy1 * wz0;
+    t.o[3] = (xin && yin) ? base + w + 1 : -1;   t.w[3] = wx1 * wy1 * wz0;
+    const int bz = base + h * w;
+    t.o[4] = zin ? bz : -1;                t.w[4] = wx0 * wy0 * wz1;
+    t.o[5] = (zin && xin) ? bz + 1 : -1;   t.w[5] = wx1 * wy0 * wz1;
+    t.o[6] = (zin && yin) ? bz + w : -1;   t.w[6] = wx0 * wy1 * wz1;
+    t.o[7] = (zin && xin && yin) ? bz + w + 1 : -1;   t.w[7] = wx1 * wy1 * wz1;
+}
+
+__device__ __forceinline__ float gather8(const float* __restrict__ plane, const Taps& t) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (t.o[k] >= 0) acc += plane[t.o[k]] * t.w[k];
+    return acc;
+}
+
+// MODE 0: out[c] = sample(src[c], coords)            (image / field warp, C channels)
+// MODE 1: out[c] = coords[c] + sample(src[c], coords) (compose, C == 3)
+// coords == nullptr -> identity map of the output grid.
+template <int MODE, int VEC>
+__global__ void __launch_bounds__(kThreads)
+sample_kernel(const float* __restrict__ src, int C, int d, int h, int w,
+              const float* __restrict__ coords, int D, int H, int W, float* __restrict__ out) {
+    const long long plane_out = (long long)D * H * W;
+    const long long plane_src = (long long)d * h * w;
+    const long long nvec = plane_out / VEC;
+    const double inz = 1.0 / (D - 1), iny = 1.0 / (H - 1), inx = 1.0 / (W - 1);
+    for (long long v = (long long)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (long long)gridDim.x * kThreads) {
+        const long long lin = v * VEC;
+        const int x = (int)(lin % W);
+        const int y = (int)((lin / W) % H);
+        const int z = (int)(lin / ((long long)W * H));
+        float cz[VEC], cy[VEC], cx[VEC];
+        if (coords) {
+            if constexpr (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(coords + lin);
+                const float4 b = *reinterpret_cast<const float4*>(coords + plane_out + lin);
+                const float4 c = *reinterpret_cast<const float4*>(coords + 2 * plane_out + lin);
+                cz[0] = a.x; cz[1] = a.y; cz[2] = a.z; cz[3] = a.w;
+                cy[0] = b.x; cy[1] = b.y; cy[2] = b.z; cy[3] = b.w;
+                cx[0] = c.x; cx[1] = c.y; cx[2] = c.z; cx[3] = c.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    cz[i] = coords[lin + i]; cy[i] = coords[plane_out + lin + i]; cx[i] = coords[2 * plane_out + lin + i];
+                }
+            }
+        } else {
+            const float fz = identity_coord(z, inz), fy = identity_coord(y, iny);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { cz[i] = fz; cy[i] = fy; cx[i] = identity_coord(x + i, inx); }
+        }
+        Taps t[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) make_taps(cz[i], cy[i], cx[i], d, h, w, t[i]);
+        for (int c = 0; c < C; ++c) {
+            const float* plane = src + c * plane_src;
+            float r[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                r[i] = gather8(plane, t[i]);
+                if constexpr (MODE == 1) r[i] += (c == 0 ? cz[i] : (c == 1 ? cy[i] : cx[i]));
+            }
+            float* o = out + c * plane_out + lin;
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+            else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] = r[i];
+            }
+        }
+    }
+}
+
+// out = identity + disp (same grid): the package's isIdentity shortcut
+__global__ void __launch_bounds__(kThreads)
+add_identity_kernel(const float* __restrict__ disp, int D, int H, int W, float* __restrict__ out) {
+    const long long plane = (long long)D * H * W;
+    const double inz = 1.0 / (D - 1), iny = 1.0 / (H - 1), inx = 1.0 / (W - 1);
+    for (long long lin = (long long)blockIdx.x * kThreads + threadIdx.x; lin < plane; lin += (long long)gridDim.x * kThreads) {
+        const int x = (int)(lin % W);
+        const int y = (int)((lin / W) % H);
+        const int z = (int)(lin / ((long long)W * H));
+        out[lin] = identity_coord(z, inz) + disp[lin];
+        out[plane + lin] = identity_coord(y, iny) + disp[plane + lin];
+        out[2 * plane + lin] = identity_coord(x, inx) + disp[2 * plane + lin];
+    }
+}
+
+// avg_pool3d(k=2, s=2, ceil_mode=True): clipped windows divide by the number of valid voxels
+__global__ void __launch_bounds__(kThreads)
+avgpool2_kernel(const float* __restrict__ in, int C, int D, int H, int W, float* __restrict__ out, int Do, int Ho, int Wo) {
+    const long long n = (long long)C * Do * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const int xo = (int)(i % Wo);
+        const int yo = (int)((i / Wo) % Ho);
+        const int zo = (int)((i / ((long long)Wo * Ho)) % Do);
+        const int c = (int)(i / ((long long)Wo * Ho * Do));
+        const int z0 = 2 * zo, y0 = 2 * yo, x0 = 2 * xo;
+        const int z1 = min(z0 + 2, D), y1 = min(y0 + 2, H), x1 = min(x0 + 2, W);
+        const float* p = in + (long long)c * D * H * W;
+        float s = 0.0f;
+        for (int z = z0; z < z1; ++z)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) s += p[((long long)z * H + y) * W + x];
+        out[i] = s / (float)((z1 - z0) * (y1 - y0) * (x1 - x0));
+    }
+}
+
+// PyTorch area_pixel_compute_source_index(align_corners=False) for linear modes
+__device__ __forceinline__ void linear_src(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ void __launch_bounds__(kThreads)
+resize_trilinear_kernel(const float* __restrict__ in, int C, int d, int h, int w,
+                        float* __restrict__ out, int D, int H, int W) {
+    const float sz = (float)d / (float)D, sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const long long n = (long long)C * D * H * W;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int z = (int)((i / ((long long)W * H)) % D);
+        const int c = (int)(i / ((long long)W * H * D));
+        int z0, z1, y0, y1, x0, x1;
+        float a0, a1, b0, b1, c0, c1;
+        linear_src(z, sz, d, z0, z1, a0, a1);
+        linear_src(y, sy, h, y0, y1, b0, b1);
+        linear_src(x, sx, w, x0, x1, c0, c1);
+        const float* p = in + (long long)c * d * h * w;
+        auto at = [&](int zz, int yy, int xx) { return p[((long long)zz * h + yy) * w + xx]; };
+        // ATen upsample_trilinear3d accumulation order
+        out[i] = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
+                 a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+phi_to_disp_kernel(const float* __restrict__ phi, int D, int H, int W, double* __restrict__ disp) {
+    const long long plane = (long long)D * H * W;
+    const double inz = 1.0 / (D - 1), iny = 1.0 / (H - 1), inx = 1.0 / (W - 1);
+    for (long long lin = (long long)blockIdx.x * kThreads + threadIdx.x; lin < plane; lin += (long long)gridDim.x * kThreads) {
+        const int x = (int)(lin % W);
+        const int y = (int)((lin / W) % H);
+        const int z = (int)(lin / ((long long)W * H));
+        // fp32 like the reference: (phi - ident) then *= (shape - 1), then .double()
+        const float dz = (phi[lin] - identity_coord(z, inz)) * (float)(D - 1);
+        const float dy = (phi[plane + lin] - identity_coord(y, iny)) * (float)(H - 1);
+        const float dx = (phi[2 * plane + lin] - identity_coord(x, inx)) * (float)(W - 1);
+        double* o = disp + 3 * lin;
+        o[0] = (double)dx; o[1] = (double)dy; o[2] = (double)dz;
+    }
+}
+
+struct Affine { double A[9]; double b[3]; };
+
+__device__ __forceinline__ void apply(const Affine& t, double x, double y, double z, double& ox, double& oy, double& oz) {
+    ox = t.A[0] * x + t.A[1] * y + t.A[2] * z + t.b[0];
+    oy = t.A[3] * x + t.A[4] * y + t.A[5] * z + t.b[1];
+    oz = t.A[6] * x + t.A[7] * y + t.A[8] * z + t.b[2];
+}
+
+__device__ __forceinline__ void clamp_split(double c, int n, int& i0, int& i1, double& f) {
+    c = fmin(fmax(c, 0.0), (double)(n - 1));
+    const double fl = floor(c);
+    i0 = (int)fl;
+    i1 = min(i0 + 1, n - 1);
+    f = c - fl;
+}
+
+// fused K19: B index -> network space -> + trilinear(disp) -> A index -> trilinear(prob), fp64 coordinates
+__global__ void __launch_bounds__(kThreads)
+resample_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
+                const double* __restrict__ disp, int Dn, int Hn, int Wn,
+                Affine b2n, Affine n2a, float* __restrict__ out, int nzB, int nyB, int nxB) {
+    const long long n = (long long)nzB * nyB * nxB;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const int xb = (int)(i % nxB);
+        const int yb = (int)((i / nxB) % nyB);
+        const int zb = (int)(i / ((long long)nxB * nyB));
+        double nx_, ny_, nz_;
+        apply(b2n, (double)xb, (double)yb, (double)zb, nx_, ny_, nz_);
+        const bool inside = nx_ >= -0.5 && nx_ < Wn - 0.5 && ny_ >= -0.5 && ny_ < Hn - 0.5 && nz_ >= -0.5 && nz_ < Dn - 0.5;
+        if (inside) {
+            int x0, x1, y0, y1, z0, z1;
+            double fx, fy, fz;
+            clamp_split(nx_, Wn, x0, x1, fx);
+            clamp_split(ny_, Hn, y0, y1, fy);
+            clamp_split(nz_, Dn, z0, z1, fz);
+            double acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                auto at = [&](int zz, int yy, int xx) { return disp[(((long long)zz * Hn + yy) * Wn + xx) * 3 + c]; };
+                const double c00 = at(z0, y0, x0) * (1 - fx) + at(z0, y0, x1) * fx;
+                const double c01 = at(z0, y1, x0) * (1 - fx) + at(z0, y1, x1) * fx;
+                const double c10 = at(z1, y0, x0) * (1 - fx) + at(z1, y0, x1) * fx;
+                const double c11 = at(z1, y1, x0) * (1 - fx) + at(z1, y1, x1) * fx;
+                acc[c] = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
+            }
+            nx_ += acc[0]; ny_ += acc[1]; nz_ += acc[2];
+        }
+        double ax, ay, az;
+        apply(n2a, nx_, ny_, nz_, ax, ay, az);
+        float r = 0.0f;
+        if (ax >= -0.5 && ax < nxA - 0.5 && ay >= -0.5 && ay < nyA - 0.5 && az >= -0.5 && az < nzA - 0.5) {
+            int x0, x1, y0, y1, z0, z1;
+            double fx, fy, fz;
+            clamp_split(ax, nxA, x0, x1, fx);
+            clamp_split(ay, nyA, y0, y1, fy);
+            clamp_split(az, nzA, z0, z1, fz);
+            auto at = [&](int zz, int yy, int xx) { return (double)prob[((long long)zz * nyA + yy) * nxA + xx]; };
+            const double c00 = at(z0, y0, x0) * (1 - fx) + at(z0, y0, x1) * fx;
+            const double c01 = at(z0, y1, x0) * (1 - fx) + at(z0, y1, x1) * fx;
+            const double c10 = at(z1, y0, x0) * (1 - fx) + at(z1, y0, x1) * fx;
+            const double c11 = at(z1, y1, x0) * (1 - fx) + at(z1, y1, x1) * fx;
+            r = (float)((c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz);
+        }
+        out[i] = r;
+    }
+}
+
+inline unsigned grid_for(long long work_items) {
+    long long blocks = (work_items + kThreads - 1) / kThreads;
+    const long long cap = 256LL * 16;            // 256 CUs x 16 blocks: grid-stride beyond that
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+template <int MODE>
+int launch_sample(const float* src, int C, int d, int h, int w, const float* coords, int D, int H, int W,
+                  float* out, hipStream_t s) {
+    const long long plane = (long long)D * H * W;
+    const bool vec4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                      (coords == nullptr || (reinterpret_cast<uintptr_t>(coords) & 15) == 0);
+    if (vec4)
+        sample_kernel<MODE, 4><<<grid_for(plane / 4), kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
+    else
+        sample_kernel<MODE, 1><<<grid_for(plane), kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oai_grid_sample3d(const float* src, int C, int d, int h, int w, const float* coords, int D, int H, int W,
+                      float* out, void* stream) {
+    OAI_CHECK_ARG(src && out, "oai_grid_sample3d: null pointer");
+    OAI_CHECK_ARG(C > 0 && d > 1 && h > 1 && w > 1 && D > 1 && H > 1 && W > 1, "oai_grid_sample3d: sizes must be > 1");
+    return launch_sample<0>(src, C, d, h, w, coords, D, H, W, out, (hipStream_t)stream);
+}
+
+int oai_compose(const float* disp, int d, int h, int w, const float* coords, int D, int H, int W, int shortcut,
+                float* out, void* stream) {
+    OAI_CHECK_ARG(disp && out, "oai_compose: null pointer");
+    OAI_CHECK_ARG(d > 1 && h > 1 && w > 1 && D > 1 && H > 1 && W > 1, "oai_compose: sizes must be > 1");
+    if (!coords && shortcut && d == D && h == H && w == W) {
+        add_identity_kernel<<<grid_for((long long)D * H * W), kThreads, 0, (hipStream_t)stream>>>(disp, D, H, W, out);
+        OAI_CHECK_LAUNCH();
+        return OAI_OK;
+    }
+    return launch_sample<1>(disp, 3, d, h, w, coords, D, H, W, out, (hipStream_t)stream);
+}
+
+int oai_avgpool2_3d(const float* in, int C, int D, int H, int W, float* out, void* stream) {
+    OAI_CHECK_ARG(in && out && C > 0 && D > 0 && H > 0 && W > 0, "oai_avgpool2_3d: bad arguments");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    avgpool2_kernel<<<grid_for((long long)C * Do * Ho * Wo), kThreads, 0, (hipStream_t)stream>>>(in, C, D, H, W, out, Do, Ho, Wo);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+int oai_resize_trilinear(const float* in, int C, int d, int h, int w, float* out, int D, int H, int W, void* stream) {
+    OAI_CHECK_ARG(in && out && C > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "oai_resize_trilinear: bad arguments");
+    resize_trilinear_kernel<<<grid_for((long long)C * D * H * W), kThreads, 0, (hipStream_t)stream>>>(in, C, d, h, w, out, D, H, W);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+int oai_phi_to_itk_displacement(const float* phi, int D, int H, int W, double* disp, void* stream) {
+    OAI_CHECK_ARG(phi && disp && D > 1 && H > 1 && W > 1, "oai_phi_to_itk_displacement: bad arguments");
+    phi_to_disp_kernel<<<grid_for((long long)D * H * W), kThreads, 0, (hipStream_t)stream>>>(phi, D, H, W, disp);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+int oai_resample_through_disp(const float* prob, int nzA, int nyA, int nxA, const double* disp, int Dn, int Hn, int Wn,
+                              const oai_affine* b2n, const oai_affine* n2a, float* out, int nzB, int nyB, int nxB,
+                              void* stream) {
+    OAI_CHECK_ARG(prob && disp && b2n && n2a && out, "oai_resample_through_disp: null pointer");
+    OAI_CHECK_ARG(nzA > 0 && nyA > 0 && nxA > 0 && Dn > 0 && Hn > 0 && Wn > 0 && nzB > 0 && nyB > 0 && nxB > 0,
+                  "oai_resample_through_disp: bad sizes");
+    Affine a, b;
+    memcpy(&a, b2n, sizeof(Affine));
+    memcpy(&b, n2a, sizeof(Affine));
+    resample_kernel<<<grid_for((long long)nzB * nyB * nxB), kThreads, 0, (hipStream_t)stream>>>(
+        prob, nzA, nyA, nxA, disp, Dn, Hn, Wn, a, b, out, nzB, nyB, nxB);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+}  // extern "C"

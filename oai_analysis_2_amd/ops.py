@@ -1,0 +1,112 @@
+"""Tensor-level wrappers over the C ABI (torch is plumbing: device memory + the current stream).
+
+Every function takes contiguous fp32 ``torch`` tensors on the HIP device, passes ``data_ptr()``
+and the current stream to liboai_hip.so, and returns the output tensor.  No torch compute op is
+used on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.OaiError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.OaiError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def grid_sample3d(src: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """src [C,d,h,w], coords [3,D,H,W] in [0,1] (None = identity of out_shape) -> [C,D,H,W]."""
+    lib = _lib.load()
+    src = _chk(src, "src")
+    Cn, d, h, w = src.shape
+    if coords is not None:
+        coords = _chk(coords, "coords")
+        D, H, W = coords.shape[1:]
+    else:
+        D, H, W = out_shape
+    out = torch.empty((Cn, D, H, W), dtype=torch.float32, device=src.device)
+    _lib.check(lib.oai_grid_sample3d(src.data_ptr(), Cn, d, h, w, coords.data_ptr() if coords is not None else None,
+                                     D, H, W, out.data_ptr(), _stream()), "oai_grid_sample3d")
+    return out
+
+
+def compose(disp: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optional[Sequence[int]] = None,
+            shortcut: bool = True) -> torch.Tensor:
+    """coords + sample(disp, coords); coords None = identity map of out_shape (or of disp's grid)."""
+    lib = _lib.load()
+    disp = _chk(disp, "disp")
+    _, d, h, w = disp.shape
+    if coords is not None:
+        coords = _chk(coords, "coords")
+        D, H, W = coords.shape[1:]
+    else:
+        D, H, W = out_shape if out_shape is not None else (d, h, w)
+    out = torch.empty((3, D, H, W), dtype=torch.float32, device=disp.device)
+    _lib.check(lib.oai_compose(disp.data_ptr(), d, h, w, coords.data_ptr() if coords is not None else None,
+                               D, H, W, int(shortcut), out.data_ptr(), _stream()), "oai_compose")
+    return out
+
+
+def avgpool2(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = _chk(x, "x")
+    Cn, D, H, W = x.shape
+    out = torch.empty((Cn, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.oai_avgpool2_3d(x.data_ptr(), Cn, D, H, W, out.data_ptr(), _stream()), "oai_avgpool2_3d")
+    return out
+
+
+def resize_trilinear(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
+    lib = _lib.load()
+    x = _chk(x, "x")
+    Cn, d, h, w = x.shape
+    D, H, W = (int(v) for v in size)
+    out = torch.empty((Cn, D, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(lib.oai_resize_trilinear(x.data_ptr(), Cn, d, h, w, out.data_ptr(), D, H, W, _stream()), "oai_resize_trilinear")
+    return out
+
+
+def phi_to_itk_displacement(phi: torch.Tensor) -> torch.Tensor:
+    """phi [3,D,H,W] -> float64 [D,H,W,3] (xyz components, network voxel units)."""
+    lib = _lib.load()
+    phi = _chk(phi, "phi")
+    _, D, H, W = phi.shape
+    out = torch.empty((D, H, W, 3), dtype=torch.float64, device=phi.device)
+    _lib.check(lib.oai_phi_to_itk_displacement(phi.data_ptr(), D, H, W, out.data_ptr(), _stream()), "oai_phi_to_itk_displacement")
+    return out
+
+
+def make_affine(A: np.ndarray, b: np.ndarray) -> _lib.Affine:
+    a = _lib.Affine()
+    a.A[:] = [float(v) for v in np.asarray(A, np.float64).reshape(9)]
+    a.b[:] = [float(v) for v in np.asarray(b, np.float64).reshape(3)]
+    return a
+
+
+def resample_through_disp(prob: torch.Tensor, disp: torch.Tensor, b_index_to_net, net_to_a_index,
+                          out_shape_zyx: Sequence[int]) -> torch.Tensor:
+    lib = _lib.load()
+    prob = _chk(prob, "prob")
+    disp = _chk(disp, "disp", torch.float64)
+    nzA, nyA, nxA = prob.shape
+    Dn, Hn, Wn, _ = disp.shape
+    nzB, nyB, nxB = (int(v) for v in out_shape_zyx)
+    out = torch.empty((nzB, nyB, nxB), dtype=torch.float32, device=prob.device)
+    a1, a2 = make_affine(*b_index_to_net), make_affine(*net_to_a_index)
+    _lib.check(lib.oai_resample_through_disp(prob.data_ptr(), nzA, nyA, nxA, disp.data_ptr(), Dn, Hn, Wn,
+                                             C.byref(a1), C.byref(a2), out.data_ptr(), nzB, nyB, nxB, _stream()),
+               "oai_resample_through_disp")
+    return out

@@ -1,0 +1,98 @@
+"""GPU parity: HIP warp family (through the C ABI) vs the oracle's torch-CPU ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oai_analysis_2_amd.synth import make_smooth_field, make_volume
+from oracle import icon as oicon
+from oracle import resample as oresample
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # north_star: displacement fields within 1e-4 rel
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("shape,src_shape", [((24, 40, 36), (24, 40, 36)), ((24, 40, 36), (12, 20, 18)),
+                                             ((17, 33, 29), (9, 17, 15)), ((160, 160, 160), (160, 160, 160))])
+def test_grid_sample_and_compose(shape, src_shape):
+    from oai_analysis_2_amd import ops
+    img = make_volume(3, src_shape)
+    field = make_smooth_field(4, src_shape, 0.03)
+    coords = (oicon.identity_map(shape)[0].numpy() + make_smooth_field(5, shape, 0.05)).astype(np.float32)
+    # push some coordinates outside [0,1] to exercise the border clamp
+    coords[:, :2] -= 0.1
+    coords[:, -2:] += 0.1
+    ref_w = oicon.sample_at(torch.from_numpy(img)[None, None], torch.from_numpy(coords)[None])[0].numpy()
+    ref_c = (torch.from_numpy(coords)[None] + oicon.sample_at(torch.from_numpy(field)[None], torch.from_numpy(coords)[None]))[0].numpy()
+    got_w = ops.grid_sample3d(_dev(img[None]), _dev(coords)).cpu().numpy()
+    got_c = ops.compose(_dev(field), _dev(coords)).cpu().numpy()
+    assert _rel(got_w, ref_w) < TOL and np.abs(got_w - ref_w).max() < 2e-6
+    assert _rel(got_c, ref_c) < TOL and np.abs(got_c - ref_c).max() < 2e-6
+
+
+def test_identity_paths():
+    from oai_analysis_2_amd import ops
+    shape, low = (20, 48, 44), (10, 24, 22)
+    d_lo = make_smooth_field(7, low, 0.04)
+    d_hi = make_smooth_field(8, shape, 0.04)
+    ident = oicon.identity_map(shape)
+    # sampled path at another resolution: id_h + sample(d_lo, id_h)
+    ref = (ident + oicon.sample_at(torch.from_numpy(d_lo)[None], ident))[0].numpy()
+    got = ops.compose(_dev(d_lo), None, out_shape=shape).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6
+    # shortcut path: identity + d, bit exact
+    ref2 = (ident + torch.from_numpy(d_hi)[None])[0].numpy()
+    got2 = ops.compose(_dev(d_hi), None, shortcut=True).cpu().numpy()
+    assert np.array_equal(got2, ref2)
+    # warping with the identity map returns the image (D-5 of SURVEY Appendix D)
+    img = make_volume(1, shape)
+    got3 = ops.grid_sample3d(_dev(img[None]), None, out_shape=shape).cpu().numpy()[0]
+    assert np.abs(got3 - img).max() < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(80, 192, 192), (5, 12, 11), (3, 6, 6)])
+def test_avgpool_ceil(shape):
+    from oai_analysis_2_amd import ops
+    x = np.stack([make_volume(2, shape), make_volume(3, shape)])
+    ref = F.avg_pool3d(torch.from_numpy(x)[None], 2, ceil_mode=True)[0].numpy()
+    got = ops.avgpool2(_dev(x)).cpu().numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("src,dst", [((160, 384, 384), (80, 192, 192)), ((30, 50, 41), (40, 48, 48)), ((20, 24, 24), (40, 48, 48))])
+def test_resize_trilinear(src, dst):
+    from oai_analysis_2_amd import ops
+    x = make_volume(6, src)
+    ref = F.interpolate(torch.from_numpy(x)[None, None], size=dst, mode="trilinear", align_corners=False)[0, 0].numpy()
+    got = ops.resize_trilinear(_dev(x[None]), dst).cpu().numpy()[0]
+    assert np.abs(got - ref).max() < 2e-6
+
+
+def test_phi_to_displacement_and_resample():
+    from oai_analysis_2_amd import ops
+    from oai_analysis_2_amd.image import Image
+    from oai_analysis_2_amd.registration import resample_affines
+    net = (20, 48, 44)
+    phi = oicon.identity_map(net) + torch.from_numpy(make_smooth_field(2, net, 0.05))[None]
+    ref_disp = oicon.displacement_itk(phi)
+    got_disp = ops.phi_to_itk_displacement(phi[0].cuda())
+    assert np.abs(got_disp.cpu().numpy() - ref_disp).max() < 1e-4
+    A = Image(make_volume(1, (40, 90, 96)), [0.36, 0.37, 0.7], [1.0, 2.0, 3.0])
+    th = 0.1
+    rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    B = Image(np.zeros((36, 100, 88), np.float32), [0.4, 0.35, 0.75], [0.0, -1.0, 2.0], rot)
+    ref = oresample.resample_through_phi(A.array.astype(np.float64), ref_disp, A, B)
+    b2n, n2a = resample_affines(A, B, net)
+    got = ops.resample_through_disp(_dev(A.array), got_disp, b2n, n2a, B.array.shape).cpu().numpy()
+    assert (ref == 0).any() and (ref != 0).any()      # exercises the outside-buffer default pixel
+    assert np.abs(got - ref).max() < 1e-5
