@@ -1,0 +1,441 @@
+// Host side of the segmentation path: weight ingest (reference layouts -> MFMA panels),
+// workspace planning, the layer schedule of UNet.forward (networks.py:109-149) with the
+// bit-identical dead-output trim, and the C ABI.
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "unet_kernels.h"
+
+namespace oai {
+
+enum LayerId { EC0, EC1, EC2, EC3, EC4, EC5, EC6, EC7, DC9, DC8, DC7, DC6, DC5, DC4, DC3, DC2, DC1, DC0 };
+static const int kLevel[18] = {0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0};   // OUTPUT level
+static const int kKind[18] = {0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 1, 2, 1, 1, 2, 1, 1, 3};
+
+struct Layer {
+    int kind = 0, cin = 0, cout = 0;
+    int c0 = 0, c1 = 0;                 // concat split of cin (c1 = skip channels)
+    float4* panel = nullptr;            // MFMA weight panel (kinds 0,1,2 except ec0)
+    float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
+    float* scale = nullptr;
+    float* shift = nullptr;
+};
+
+}  // namespace oai
+
+struct oai_unet {
+    oai::Layer L[18];
+    int variant = 0;                    // 0: MREP4/KC8, 1: MREP2/KC16
+    int n_classes = 0;
+    std::vector<void*> allocs;
+};
+
+namespace oai {
+
+static int conv_kc(int variant) { return variant == 1 ? 16 : 8; }
+
+// Wk[tap][cin][cout] of the equivalent correlation (Conv3d as is; ConvTranspose3d k3 s1 p1 = conv with
+// the kernel flipped and in/out swapped).
+static std::vector<float> canonical_k3(const oai_layer_params& p) {
+    std::vector<float> w((size_t)27 * p.cin * p.cout);
+    for (int t = 0; t < 27; ++t)
+        for (int ci = 0; ci < p.cin; ++ci)
+            for (int co = 0; co < p.cout; ++co) {
+                float v;
+                if (p.kind == 0) v = p.weight_host[((size_t)co * p.cin + ci) * 27 + t];
+                else v = p.weight_host[((size_t)ci * p.cout + co) * 27 + (26 - t)];   // flip all three axes
+                w[((size_t)t * p.cin + ci) * p.cout + co] = v;
+            }
+    return w;
+}
+
+// Panel order = consumption order of conv3_igemm_f32: [cb][chunk][tap][kg][nr][lane] x float4, where the
+// float4 of lane (half h, column j) holds channels 4h..4h+3 of the k-group for cout cb*64+nr*32+j.
+static std::vector<float> pack_conv3_panel(const std::vector<float>& wk, int C0, int C1, int Cout, int KC) {
+    const int Cin = C0 + C1, KG = KC / 8;
+    const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+    std::vector<float> out(((size_t)ncb * (nch0 + nch1) * 27 * KG * 2 + 2) * 64 * 4, 0.0f);   // +1 step of prefetch slack
+    size_t o = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nch0 + nch1; ++ch) {
+            const bool first = ch < nch0;
+            const int Csrc = first ? C0 : C1, cofs = first ? 0 : C0, cl0 = (first ? ch : ch - nch0) * KC;
+            for (int t = 0; t < 27; ++t)
+                for (int kg = 0; kg < KG; ++kg)
+                    for (int nr = 0; nr < 2; ++nr)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int s = 0; s < 4; ++s, ++o) {
+                                const int cl = cl0 + kg * 8 + 4 * (lane >> 5) + s;
+                                const int co = cb * 64 + nr * 32 + (lane & 31);
+                                if (cl < Csrc && co < Cout) out[o] = wk[((size_t)t * Cin + cofs + cl) * Cout + co];
+                            }
+        }
+    return out;
+}
+
+// [N/64][Cin/8][2][lane] x float4 for upconv2_igemm_f32; column n = parity*Cout + co
+static std::vector<float> pack_up_panel(const oai_layer_params& p) {
+    const int N = 8 * p.cout, nnb = (N + 63) / 64, nkg = (p.cin + 7) / 8;
+    std::vector<float> out((size_t)nnb * nkg * 2 * 64 * 4, 0.0f);
+    size_t o = 0;
+    for (int nb = 0; nb < nnb; ++nb)
+        for (int kg = 0; kg < nkg; ++kg)
+            for (int nr = 0; nr < 2; ++nr)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s, ++o) {
+                        const int ci = kg * 8 + 4 * (lane >> 5) + s;
+                        const int col = nb * 64 + nr * 32 + (lane & 31);
+                        if (ci < p.cin && col < N) {
+                            const int par = col / p.cout, co = col % p.cout;
+                            out[o] = p.weight_host[((size_t)ci * p.cout + co) * 8 + par];   // [ci][co][a][b][c]
+                        }
+                    }
+    return out;
+}
+
+template <typename T>
+static int upload(oai_unet* h, const std::vector<float>& v, T** dst) {
+    void* d = nullptr;
+    OAI_CHECK_HIP(hipMalloc(&d, v.size() * sizeof(float)));
+    h->allocs.push_back(d);
+    OAI_CHECK_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<T*>(d);
+    return OAI_OK;
+}
+
+struct Box { int lo[3], hi[3]; };
+
+static void full_box(Box& b, const int dims[3]) { for (int i = 0; i < 3; ++i) { b.lo[i] = 0; b.hi[i] = dims[i]; } }
+
+// Output box each layer must produce so that the kept centre is unchanged (oracle/seg.py:trim_regions)
+static void plan_regions(const int tile[3], const int keep_lo[3], const int keep_hi[3], bool trimmed, Box need[18]) {
+    int dims[4][3];
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) dims[l][i] = tile[i] >> l;
+    for (int k = 0; k < 18; ++k) full_box(need[k], dims[kLevel[k]]);
+    if (!trimmed) return;
+    auto grow = [&](const Box& b, int lvl) { Box r; for (int i = 0; i < 3; ++i) { r.lo[i] = b.lo[i] > 0 ? b.lo[i] - 1 : 0; r.hi[i] = b.hi[i] + 1 < dims[lvl][i] ? b.hi[i] + 1 : dims[lvl][i]; } return r; };
+    auto halve = [&](const Box& b) { Box r; for (int i = 0; i < 3; ++i) { r.lo[i] = b.lo[i] / 2; r.hi[i] = (b.hi[i] + 1) / 2; } return r; };
+    Box keep; for (int i = 0; i < 3; ++i) { keep.lo[i] = keep_lo[i]; keep.hi[i] = keep_hi[i]; }
+    need[DC0] = keep; need[DC1] = keep;
+    need[DC2] = grow(need[DC1], 0);
+    need[DC3] = grow(need[DC2], 0);
+    need[DC4] = halve(need[DC3]);
+    need[DC5] = grow(need[DC4], 1);
+    need[DC6] = grow(need[DC5], 1);
+    need[DC7] = halve(need[DC6]);
+    need[DC8] = grow(need[DC7], 2);
+    // dc9 and the encoder stay full: the bottleneck sees the whole tile
+}
+
+struct Plan {
+    size_t off[24];
+    size_t total;
+};
+enum Buf { B_E0, B_SYN0, B_P0, B_E2, B_SYN1, B_P1, B_E4, B_SYN2, B_P2, B_E6, B_E7, B_U9, B_D8, B_D7, B_U6, B_D5, B_D4, B_U3, B_D2, B_D1, B_COUNT };
+
+static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch) {
+    const size_t v0 = (size_t)td * th * tw, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;
+    const oai::Layer* L = h->L;
+    const size_t sizes[B_COUNT] = {
+        v0 * L[EC0].cout, v0 * L[EC1].cout, v1 * L[EC1].cout, v1 * L[EC2].cout, v1 * L[EC3].cout, v2 * L[EC3].cout,
+        v2 * L[EC4].cout, v2 * L[EC5].cout, v3 * L[EC5].cout, v3 * L[EC6].cout, v3 * L[EC7].cout, v2 * L[DC9].cout,
+        v2 * L[DC8].cout, v2 * L[DC7].cout, v1 * L[DC6].cout, v1 * L[DC5].cout, v1 * L[DC4].cout, v0 * L[DC3].cout,
+        v0 * L[DC2].cout, v0 * L[DC1].cout};
+    Plan p;
+    size_t o = 0;
+    for (int i = 0; i < B_COUNT; ++i) {
+        p.off[i] = o;
+        o += ((sizes[i] * batch * sizeof(float) + 255) / 256) * 256;
+    }
+    p.total = o;
+    return p;
+}
+
+static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
+                        const int dims[3], const Box& box, int ntiles, hipStream_t st) {
+    ConvArgs a;
+    a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
+    a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
+    a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
+    for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
+    const int TZ = h->variant == 1 ? 2 : 4;
+    a.nbz = cdiv(box.hi[0] - box.lo[0], TZ);
+    a.nby = cdiv(box.hi[1] - box.lo[1], kConvTY);
+    a.nbx = cdiv(box.hi[2] - box.lo[2], kConvTX);
+    a.ncb = (L.cout + 63) / 64;
+    a.relu = 1;
+    const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    if (h->variant == 1) conv3_igemm_f32<2, 16><<<grid, 256, 0, st>>>(a);
+    else conv3_igemm_f32<4, 8><<<grid, 256, 0, st>>>(a);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+static int launch_up(const Layer& L, const float* src, float* out, const int in_dims[3], const Box& out_need,
+                     int ntiles, hipStream_t st) {
+    UpArgs a;
+    a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
+    a.D = in_dims[0]; a.H = in_dims[1]; a.W = in_dims[2];
+    for (int i = 0; i < 3; ++i) { a.lo[i] = out_need.lo[i] / 2; a.hi[i] = (out_need.hi[i] + 1) / 2; }
+    const int nvox = (a.hi[0] - a.lo[0]) * (a.hi[1] - a.lo[1]) * (a.hi[2] - a.lo[2]);
+    a.nmb = cdiv(nvox, 64);
+    a.nnb = cdiv(8 * L.cout, 256);
+    a.relu = 1;
+    upconv2_igemm_f32<<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+static int launch_pool(const float* in, float* out, const int dims[3], int C, int ntiles, hipStream_t st) {
+    const size_t total4 = (size_t)ntiles * (dims[0] / 2) * (dims[1] / 2) * (dims[2] / 2) * (C / 4);
+    size_t blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    maxpool2_kernel<<<(unsigned)blocks, 256, 0, st>>>(in, out, dims[0], dims[1], dims[2], C, total4);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+// One batch of `n` tiles through the whole network; kept-centre blocks go to blocks_out.
+static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[18], int out_mode,
+                     float* blocks_out, char* ws, const Plan& plan, hipStream_t st) {
+    const Layer* L = h->L;
+    float* buf[B_COUNT];
+    for (int i = 0; i < B_COUNT; ++i) buf[i] = reinterpret_cast<float*>(ws + plan.off[i]);
+    int d[4][3];
+    for (int l = 0; l < 4; ++l) { d[l][0] = src.td >> l; d[l][1] = src.th >> l; d[l][2] = src.tw >> l; }
+    const size_t v0 = (size_t)src.td * src.th * src.tw;
+
+    {   // ec0 (+ gather)
+        dim3 grid(cdiv(v0, 256), L[EC0].cout / 8, n);
+        conv3_first_kernel<<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], L[EC0].cout, 1);
+        OAI_CHECK_LAUNCH();
+    }
+    int rc;
+#define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
+    RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st));
+    RUN(launch_pool(buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
+    RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st));
+    RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st));
+    RUN(launch_pool(buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
+    RUN(launch_conv3(h, L[EC4], buf[B_P1], nullptr, buf[B_E4], d[2], need[EC4], n, st));
+    RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st));
+    RUN(launch_pool(buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
+    RUN(launch_conv3(h, L[EC6], buf[B_P2], nullptr, buf[B_E6], d[3], need[EC6], n, st));
+    RUN(launch_conv3(h, L[EC7], buf[B_E6], nullptr, buf[B_E7], d[3], need[EC7], n, st));
+    RUN(launch_up(L[DC9], buf[B_E7], buf[B_U9], d[3], need[DC9], n, st));
+    RUN(launch_conv3(h, L[DC8], buf[B_U9], buf[B_SYN2], buf[B_D8], d[2], need[DC8], n, st));   // cat(up, skip) :127
+    RUN(launch_conv3(h, L[DC7], buf[B_D8], nullptr, buf[B_D7], d[2], need[DC7], n, st));
+    RUN(launch_up(L[DC6], buf[B_D7], buf[B_U6], d[2], need[DC6], n, st));
+    RUN(launch_conv3(h, L[DC5], buf[B_U6], buf[B_SYN1], buf[B_D5], d[1], need[DC5], n, st));   // :134
+    RUN(launch_conv3(h, L[DC4], buf[B_D5], nullptr, buf[B_D4], d[1], need[DC4], n, st));
+    RUN(launch_up(L[DC3], buf[B_D4], buf[B_U3], d[1], need[DC3], n, st));
+    RUN(launch_conv3(h, L[DC2], buf[B_U3], buf[B_SYN0], buf[B_D2], d[0], need[DC2], n, st));   // :141
+    RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC1], n, st));
+#undef RUN
+    {   // dc0 + sigmoid/threshold + centre crop
+        const Box& k = need[DC0];
+        const int bz = k.hi[0] - k.lo[0], by = k.hi[1] - k.lo[1], bx = k.hi[2] - k.lo[2];
+        dim3 grid(cdiv((size_t)bz * by * bx, 256), n);
+        head_kernel<<<grid, 256, 0, st>>>(buf[B_D1], L[DC0].cin, d[0][0], d[0][1], d[0][2], k.lo[0], k.lo[1], k.lo[2],
+                                          bz, by, bx, L[DC0].plain, L[DC0].shift, h->n_classes, out_mode, blocks_out);
+        OAI_CHECK_LAUNCH();
+    }
+    return OAI_OK;
+}
+
+static double layer_flops(const oai_unet* h, int k, const Box& b) {
+    const double vox = (double)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
+    const int taps = (kKind[k] == 0 || kKind[k] == 1) ? 27 : 1;
+    return 2.0 * vox * taps * h->L[k].cin * h->L[k].cout;
+}
+
+}  // namespace oai
+
+using namespace oai;
+
+extern "C" {
+
+int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn_eps, oai_unet** out) {
+    OAI_CHECK_ARG(layers && out, "oai_unet_create: null pointer");
+    for (int k = 0; k < 18; ++k) {
+        OAI_CHECK_ARG(layers[k].weight_host, "oai_unet_create: layer %d has no weight (strict load)", k);
+        OAI_CHECK_ARG(layers[k].kind == kKind[k], "oai_unet_create: layer %d kind %d, expected %d", k, layers[k].kind, kKind[k]);
+        OAI_CHECK_ARG(layers[k].cin > 0 && layers[k].cout > 0, "oai_unet_create: layer %d bad channels", k);
+    }
+    // channel wiring of UNet.__init__ (networks.py:43-66)
+    const int chain[][2] = {{EC0, EC1}, {EC1, EC2}, {EC2, EC3}, {EC3, EC4}, {EC4, EC5}, {EC5, EC6}, {EC6, EC7}, {EC7, DC9},
+                            {DC8, DC7}, {DC7, DC6}, {DC5, DC4}, {DC4, DC3}, {DC2, DC1}, {DC1, DC0}};
+    for (auto& c : chain)
+        OAI_CHECK_ARG(layers[c[0]].cout == layers[c[1]].cin, "oai_unet_create: layer %d cout != layer %d cin", c[0], c[1]);
+    OAI_CHECK_ARG(layers[DC8].cin == layers[DC9].cout + layers[EC5].cout, "oai_unet_create: dc8 cin != dc9 + ec5");
+    OAI_CHECK_ARG(layers[DC5].cin == layers[DC6].cout + layers[EC3].cout, "oai_unet_create: dc5 cin != dc6 + ec3");
+    OAI_CHECK_ARG(layers[DC2].cin == layers[DC3].cout + layers[EC1].cout, "oai_unet_create: dc2 cin != dc3 + ec1");
+    OAI_CHECK_ARG(layers[EC0].cin == 1, "oai_unet_create: only in_channels == 1 is supported (the reference's config)");
+    OAI_CHECK_ARG(layers[DC0].cout <= 4, "oai_unet_create: n_classes must be <= 4");
+    for (int k = 0; k < 18; ++k) {
+        OAI_CHECK_ARG(k == EC0 || layers[k].cin % 8 == 0, "oai_unet_create: layer %d cin must be a multiple of 8", k);
+        OAI_CHECK_ARG(k == DC0 || layers[k].cout % 8 == 0, "oai_unet_create: layer %d cout must be a multiple of 8", k);
+    }
+
+    oai_unet* h = new oai_unet();
+    const char* env = getenv("OAI_CONV_VARIANT");
+    h->variant = env ? atoi(env) : 0;
+    h->n_classes = layers[DC0].cout;
+    const int KC = conv_kc(h->variant);
+    int rc = OAI_OK;
+    for (int k = 0; k < 18 && rc == OAI_OK; ++k) {
+        const oai_layer_params& p = layers[k];
+        Layer& L = h->L[k];
+        L.kind = p.kind; L.cin = p.cin; L.cout = p.cout; L.c0 = p.cin; L.c1 = 0;
+        if (k == DC8) { L.c0 = layers[DC9].cout; L.c1 = layers[EC5].cout; }
+        if (k == DC5) { L.c0 = layers[DC6].cout; L.c1 = layers[EC3].cout; }
+        if (k == DC2) { L.c0 = layers[DC3].cout; L.c1 = layers[EC1].cout; }
+        // epilogue affine: eval-mode BatchNorm3d folded with the conv bias (per channel, weights untouched)
+        std::vector<float> sc(p.cout, 1.0f), sh(p.cout, 0.0f);
+        for (int c = 0; c < p.cout; ++c) {
+            const float b = p.bias_host ? p.bias_host[c] : 0.0f;
+            if (p.bn_gamma_host) {
+                const float s = p.bn_gamma_host[c] / sqrtf(p.bn_var_host[c] + bn_eps);
+                sc[c] = s;
+                sh[c] = (b - p.bn_mean_host[c]) * s + p.bn_beta_host[c];
+            } else sh[c] = b;
+        }
+        if ((rc = upload(h, sc, &L.scale))) break;
+        if ((rc = upload(h, sh, &L.shift))) break;
+        if (k == EC0) {
+            std::vector<float> wk = canonical_k3(p);          // [27][1][cout]
+            rc = upload(h, wk, &L.plain);
+        } else if (p.kind == 0 || p.kind == 1) {
+            std::vector<float> wk = canonical_k3(p);
+            rc = upload(h, pack_conv3_panel(wk, L.c0, L.c1, p.cout, KC), &L.panel);
+        } else if (p.kind == 2) {
+            rc = upload(h, pack_up_panel(p), &L.panel);
+        } else {
+            std::vector<float> w(p.weight_host, p.weight_host + (size_t)p.cout * p.cin);
+            rc = upload(h, w, &L.plain);
+        }
+    }
+    if (rc != OAI_OK) { oai_unet_destroy(h); return rc; }
+    *out = h;
+    return OAI_OK;
+}
+
+void oai_unet_destroy(oai_unet* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+size_t oai_unet_workspace_bytes(const oai_unet* h, int td, int th, int tw, int batch) {
+    if (!h || td <= 0 || th <= 0 || tw <= 0 || batch <= 0) return 0;
+    return plan_workspace(h, td, th, tw, batch).total;
+}
+
+double oai_unet_tile_flops(const oai_unet* h, int td, int th, int tw, const int overlap[3], int trimmed) {
+    if (!h) return 0.0;
+    const int tile[3] = {td, th, tw};
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) { lo[i] = overlap ? overlap[i] : 0; hi[i] = tile[i] - lo[i]; }
+    Box need[18];
+    plan_regions(tile, lo, hi, trimmed != 0, need);
+    double f = 0;
+    for (int k = 0; k < 18; ++k) f += layer_flops(h, k, need[k]);
+    return f;
+}
+
+static int check_tile(int td, int th, int tw) {
+    OAI_CHECK_ARG(td >= 8 && th >= 8 && tw >= 8 && td % 8 == 0 && th % 8 == 0 && tw % 8 == 0,
+                  "tile size %dx%dx%d must be a positive multiple of 8 per axis (three 2x poolings)", td, th, tw);
+    return OAI_OK;
+}
+
+int oai_unet_forward_tiles(oai_unet* h, const float* tiles, float* logits, int B, int td, int th, int tw,
+                           void* ws, size_t ws_bytes, void* stream) {
+    OAI_CHECK_ARG(h && tiles && logits && ws, "oai_unet_forward_tiles: null pointer");
+    OAI_CHECK_ARG(B > 0, "oai_unet_forward_tiles: B must be > 0");
+    if (int rc = check_tile(td, th, tw)) return rc;
+    // as many tiles per pass as the workspace holds
+    int batch = B;
+    while (batch > 1 && plan_workspace(h, td, th, tw, batch).total > ws_bytes) --batch;
+    const Plan plan = plan_workspace(h, td, th, tw, batch);
+    if (plan.total > ws_bytes)
+        return set_error(OAI_ERR_WORKSPACE, "oai_unet_forward_tiles: workspace %zu B < %zu B needed for one tile", ws_bytes, plan.total);
+    const int tile[3] = {td, th, tw};
+    const int lo[3] = {0, 0, 0};
+    Box need[18];
+    plan_regions(tile, lo, tile, false, need);
+    TileSource src{};
+    src.vol = nullptr; src.td = td; src.th = th; src.tw = tw;
+    const size_t v0 = (size_t)td * th * tw;
+    for (int s = 0; s < B; s += batch) {
+        const int n = B - s < batch ? B - s : batch;
+        src.tiles = tiles + (size_t)s * v0;
+        src.tile_begin = 0;
+        if (int rc = run_batch(h, src, n, need, 2, logits + (size_t)s * h->n_classes * v0, (char*)ws, plan, (hipStream_t)stream)) return rc;
+    }
+    return OAI_OK;
+}
+
+int oai_segment_tiles(oai_unet* h, const float* vol, int D, int H, int W, const int tile[3], const int overlap[3],
+                      int tile_begin, int tile_end, int out_mode, float* blocks, int batch,
+                      void* ws, size_t ws_bytes, void* stream) {
+    OAI_CHECK_ARG(h && vol && tile && overlap && blocks && ws, "oai_segment_tiles: null pointer");
+    OAI_CHECK_ARG(D > 1 && H > 1 && W > 1, "oai_segment_tiles: volume axes must be > 1 (reflect padding)");
+    OAI_CHECK_ARG(out_mode >= 0 && out_mode <= 2, "oai_segment_tiles: out_mode must be 0, 1 or 2");
+    if (int rc = check_tile(tile[0], tile[1], tile[2])) return rc;
+    int eff[3], grid[3];
+    const int size[3] = {D, H, W};
+    for (int i = 0; i < 3; ++i) {
+        OAI_CHECK_ARG(overlap[i] >= 0 && tile[i] - 2 * overlap[i] > 0, "oai_segment_tiles: overlap too large for the tile");
+        eff[i] = tile[i] - 2 * overlap[i];
+        grid[i] = (size[i] + eff[i] - 1) / eff[i];
+    }
+    const int ntiles = grid[0] * grid[1] * grid[2];
+    OAI_CHECK_ARG(0 <= tile_begin && tile_begin <= tile_end && tile_end <= ntiles,
+                  "oai_segment_tiles: tile range [%d,%d) outside [0,%d)", tile_begin, tile_end, ntiles);
+    OAI_CHECK_ARG(batch > 0, "oai_segment_tiles: batch must be > 0");
+    const Plan plan = plan_workspace(h, tile[0], tile[1], tile[2], batch);
+    if (plan.total > ws_bytes)
+        return set_error(OAI_ERR_WORKSPACE, "oai_segment_tiles: workspace %zu B < %zu B needed for batch %d", ws_bytes, plan.total, batch);
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) { lo[i] = overlap[i]; hi[i] = tile[i] - overlap[i]; }
+    Box need[18];
+    const char* notrim = getenv("OAI_NO_TRIM");
+    plan_regions(tile, lo, hi, !(notrim && atoi(notrim)), need);
+    TileSource src{};
+    src.vol = vol; src.tiles = nullptr; src.D = D; src.H = H; src.W = W;
+    src.td = tile[0]; src.th = tile[1]; src.tw = tile[2];
+    src.ez = eff[0]; src.ey = eff[1]; src.ex = eff[2];
+    src.oz = overlap[0]; src.oy = overlap[1]; src.ox = overlap[2];
+    src.gy = grid[1]; src.gx = grid[2];
+    const size_t bvox = (size_t)eff[0] * eff[1] * eff[2];
+    for (int t = tile_begin; t < tile_end; t += batch) {
+        const int n = tile_end - t < batch ? tile_end - t : batch;
+        src.tile_begin = t;
+        if (int rc = run_batch(h, src, n, need, out_mode, blocks + (size_t)(t - tile_begin) * h->n_classes * bvox,
+                               (char*)ws, plan, (hipStream_t)stream)) return rc;
+    }
+    return OAI_OK;
+}
+
+int oai_stitch_blocks(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],
+                      const int crop[3], float* maps, void* stream) {
+    OAI_CHECK_ARG(blocks && maps && tile && overlap, "oai_stitch_blocks: null pointer");
+    int eff[3], grid[3];
+    const int size[3] = {D, H, W};
+    for (int i = 0; i < 3; ++i) {
+        eff[i] = tile[i] - 2 * overlap[i];
+        OAI_CHECK_ARG(eff[i] > 0, "oai_stitch_blocks: overlap too large for the tile");
+        grid[i] = (size[i] + eff[i] - 1) / eff[i];
+    }
+    const size_t total = (size_t)ncls * D * H * W;
+    size_t nblk = (total + 255) / 256;
+    if (nblk > 256 * 32) nblk = 256 * 32;
+    stitch_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(blocks, ncls, D, H, W, eff[0], eff[1], eff[2], grid[1], grid[2],
+                                                                crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, maps);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,408 @@
+// Device kernels of the 3D U-Net segmentation path (gfx950).  Included by unet.hip only.
+//
+// Layout: every activation is channels-last  [tile][z][y][x][c]  fp32, so that the GEMM K
+// dimension (input channels of one tap) is contiguous and an output row of 32 couts is one
+// 128-byte store.  Tiles are never materialised from the volume: ec0 gathers its 27 inputs
+// straight from the resident volume with reflect-pad index math (Partition.__call__,
+// image_transforms.py:395-455), and the head writes only the kept centre block of each tile.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace oai {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM 3x3x3 convolution on v_mfma_f32_32x32x2_f32  (M = voxels, N = cout, K = 27*cin).
+//
+// Workgroup = 4 waves, output tile  TZ(=MREP) x 8 x 16 voxels  x  64 couts.
+//   wave w owns the y-pair {2w, 2w+1}; its MREP row blocks are the z slices of the tile; one MFMA
+//   row block (32 rows) = 16 x by 2 y voxels.  Each wave holds MREP x 2 accumulators of 32x32.
+// K loop: chunks of KC input channels.  Per chunk the (TZ+2) x 10 x 18 halo box of the input is
+//   staged once into LDS (zero-filled outside the tile: Conv3d padding=1 at the TILE border,
+//   networks.py:82) and reused by all 27 taps and both cout blocks.
+// A fragments: one ds_read_b128 per row block gives the lane 4 consecutive channels = 4 MFMA
+//   k-steps (lane half h supplies channels 4h..4h+3, so k is permuted identically in A and B).
+// B fragments: weights are pre-packed on the host into per-lane float4 panels in exactly the order
+//   the loop consumes them; every wave streams them from L2 with coalesced 1-KiB loads, one step
+//   ahead of the MFMAs that use them.  No LDS, no barrier for B.
+// Numerics: exact fp32 products, fp32 accumulation (an fmaf chain in k order), like the
+//   reference's fp32 CPU path up to summation order.
+// ---------------------------------------------------------------------------------------------
+
+struct ConvArgs {
+    const float* src0; const float* src1;   // concat (src0, src1) along channels; src1 may be null
+    int C0, C1;
+    float* out; int Cout;
+    const float4* wpanel;                    // packed weights (see pack_conv3_panel)
+    const float* scale; const float* shift;  // per-cout epilogue: relu(acc*scale + shift)
+    int D, H, W;                             // spatial dims of this level (per tile)
+    int lo[3], hi[3];                        // output box to compute, [lo,hi) in z,y,x
+    int nbz, nby, nbx, ncb;                  // spatial blocks, cout blocks of 64
+    int relu;
+};
+
+constexpr int kConvTY = 8, kConvTX = 16, kConvHY = kConvTY + 2, kConvHX = kConvTX + 2;
+
+template <int MREP, int KC>
+__global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
+    constexpr int NREP = 2;
+    constexpr int TZ = MREP, HZ = TZ + 2;
+    constexpr int STRIDE = KC + 4;                 // floats per halo voxel (16-byte pad: bank spread)
+    constexpr int HVOX = HZ * kConvHY * kConvHX;
+    constexpr int Q = KC / 4;                      // float4 per voxel per chunk
+    constexpr int KG = KC / 8;                     // k-groups (8 channels = 4 MFMA steps) per chunk
+    __shared__ __attribute__((aligned(16))) float lds[HVOX * STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = blockIdx.x;
+    const int cb = id % a.ncb; id /= a.ncb;
+    const int bx = id % a.nbx; id /= a.nbx;
+    const int by = id % a.nby; id /= a.nby;
+    const int bz = id % a.nbz; id /= a.nbz;
+    const int tile = id;
+    const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * kConvTY, ox0 = a.lo[2] + bx * kConvTX;
+
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int row = lane & 31, half = lane >> 5;
+    const int lx = row & 15, ly = 2 * wave + (row >> 4);
+    // LDS float offset of this lane's voxel for row block m, tap (0,0,0)
+    const int a_base = (ly * kConvHX + lx) * STRIDE + 4 * half;
+
+    const int nch0 = (a.C0 + KC - 1) / KC, nch1 = (a.C1 + KC - 1) / KC;
+    const int nchunks = nch0 + nch1;
+    const float4* wp = a.wpanel + (size_t)cb * nchunks * 27 * KG * NREP * 64 + lane;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+
+    float4 bnext[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
+    wp += NREP * 64;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool first = ch < nch0;
+        const float* src = first ? a.src0 : a.src1;
+        const int C = first ? a.C0 : a.C1;
+        const int c0 = (first ? ch : ch - nch0) * KC;
+        const float* sbase = src + (size_t)tile * plane * C + c0;
+        __syncthreads();                                     // all waves done with the previous chunk
+        for (int slot = tid; slot < HVOX * Q; slot += 256) {
+            const int hv = slot / Q, q = slot - hv * Q;
+            const int hx = hv % kConvHX;
+            const int t2 = hv / kConvHX;
+            const int hy = t2 % kConvHY, hz = t2 / kConvHY;
+            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                c0 + 4 * q < C)
+                v = *reinterpret_cast<const float4*>(sbase + (((size_t)gz * a.H + gy) * a.W + gx) * C + 4 * q);
+            *reinterpret_cast<float4*>(&lds[hv * STRIDE + 4 * q]) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+            for (int dyx = 0; dyx < 9; ++dyx) {
+                const int dy = dyx / 3, dx = dyx % 3;
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) {
+                    float4 bcur[NREP];
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) { bcur[n] = bnext[n]; bnext[n] = wp[n * 64]; }
+                    wp += NREP * 64;
+                    float4 af[MREP];
+#pragma unroll
+                    for (int m = 0; m < MREP; ++m)
+                        af[m] = *reinterpret_cast<const float4*>(
+                            &lds[a_base + (((m + dz) * kConvHY + dy) * kConvHX + dx) * STRIDE + 8 * kg]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                        for (int m = 0; m < MREP; ++m) {
+                            const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+#pragma unroll
+                            for (int n = 0; n < NREP; ++n) {
+                                const float bv = s == 0 ? bcur[n].x : s == 1 ? bcur[n].y : s == 2 ? bcur[n].z : bcur[n].w;
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = cb * 64 + n * 32 + row;
+        if (co >= a.Cout) continue;
+        const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            const int oz = oz0 + m;
+            if (oz >= a.hi[0]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ox = ox0 + (rr & 15), oy = oy0 + 2 * wave + (rr >> 4);
+                if (ox < a.hi[2] && oy < a.hi[1]) {
+                    float v = acc[m][n][r] * sc + sh;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    a.out[((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvTranspose3d(k=2, s=2): out[2i+a][2j+b][2k+c][co] = sum_ci x[i][j][k][ci] * W[ci][co][a][b][c]
+// (networks.py:56,59,62).  One GEMM with M = input voxels, K = cin, N = 8*cout (column n =
+// parity*cout + co), the store scatters each column to its parity's output voxel.
+// A and B fragments come straight from global/L2 (no reuse worth staging: 3 % of the FLOPs).
+// Workgroup = 4 waves sharing the same 64 input voxels, each wave a different 64-column slab.
+// ---------------------------------------------------------------------------------------------
+
+struct UpArgs {
+    const float* src; int Cin;
+    float* out; int Cout;
+    const float4* wpanel;               // [N/64][Cin/8][2][64] float4
+    const float* scale; const float* shift;
+    int D, H, W;                        // INPUT level dims
+    int lo[3], hi[3];                   // INPUT box needed, z,y,x
+    int nmb;                            // row blocks of 64 voxels per tile
+    int nnb;                            // column groups of 256
+    int relu;
+};
+
+__global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = blockIdx.x;
+    const int nb = id % a.nnb; id /= a.nnb;
+    const int mb = id % a.nmb; id /= a.nmb;
+    const int tile = id;
+    const int N = 8 * a.Cout;
+    const int ncol0 = nb * 256 + wave * 64;
+    if (ncol0 >= N) return;
+    const int row = lane & 31, half = lane >> 5;
+    const int rz = a.hi[0] - a.lo[0], ry = a.hi[1] - a.lo[1], rx = a.hi[2] - a.lo[2];
+    const int nvox = rz * ry * rx;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+
+    // this lane's A rows (two row blocks of 32 voxels)
+    const float* ap[2];
+    bool av[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int v = mb * 64 + m * 32 + row;
+        av[m] = v < nvox;
+        const int vv = av[m] ? v : 0;
+        const int x = vv % rx, y = (vv / rx) % ry, z = vv / (rx * ry);
+        ap[m] = a.src + ((size_t)tile * plane + ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) * a.Cin + 4 * half;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int nkg = (a.Cin + 7) / 8;
+    const float4* wp = a.wpanel + (size_t)(ncol0 / 64) * nkg * 2 * 64 + lane;
+    for (int kg = 0; kg < nkg; ++kg) {
+        float4 af[2], bf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            af[m] = (av[m] && kg * 8 + 4 * half < a.Cin) ? *reinterpret_cast<const float4*>(ap[m] + kg * 8)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = wp[(kg * 2 + n) * 64];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float x = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float y = s == 0 ? bf[n].x : s == 1 ? bf[n].y : s == 2 ? bf[n].z : bf[n].w;
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[m][n], 0, 0, 0);
+                }
+            }
+    }
+    const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+    (void)Do;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = ncol0 + n * 32 + row;
+        if (col >= N) continue;
+        const int par = col / a.Cout, co = col - par * a.Cout;
+        const int pa = par >> 2, pb = (par >> 1) & 1, pc = par & 1;
+        const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int v = mb * 64 + m * 32 + rr;
+                if (v < nvox) {
+                    const int x = v % rx, y = (v / rx) % ry, z = v / (rx * ry);
+                    const int oz = 2 * (a.lo[0] + z) + pa, oy = 2 * (a.lo[1] + y) + pb, ox = 2 * (a.lo[2] + x) + pc;
+                    float val = acc[m][n][r] * sc + sh;
+                    if (a.relu) val = fmaxf(val, 0.0f);
+                    a.out[((size_t)tile * 8 * plane + ((size_t)oz * Ho + oy) * Wo + ox) * a.Cout + co] = val;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ec0: Conv3d(1 -> cout, k3, p1) + ReLU, fused with the overlap-tile gather.  Memory/VALU bound
+// (K = 27): one thread = one voxel x 8 couts, weights through the scalar cache.
+// ---------------------------------------------------------------------------------------------
+
+struct TileSource {
+    const float* vol;        // resident volume [D][H][W]  (or null)
+    const float* tiles;      // explicit tiles [n][td][th][tw] (B3 seam) when vol == null
+    int D, H, W;
+    int td, th, tw;          // tile size
+    int ez, ey, ex;          // effective (kept) size = tile - 2*overlap
+    int oz, oy, ox;          // overlap
+    int gy, gx;              // tile grid (y, x); z-major tile order ind = (i*gy + j)*gx + k
+    int tile_begin;          // global index of local tile 0
+};
+
+__device__ __forceinline__ int reflect_index(int v, int n) {
+    // numpy.pad(mode='reflect'): period 2(n-1), no edge repeat
+    const int p = 2 * (n - 1);
+    int m = v % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - m;
+}
+
+__device__ __forceinline__ float tile_voxel(const TileSource& s, int local_tile, int z, int y, int x) {
+    if ((unsigned)z >= (unsigned)s.td || (unsigned)y >= (unsigned)s.th || (unsigned)x >= (unsigned)s.tw) return 0.0f;
+    if (!s.vol) return s.tiles[(((size_t)local_tile * s.td + z) * s.th + y) * s.tw + x];
+    const int t = s.tile_begin + local_tile;
+    const int tk = t % s.gx, tj = (t / s.gx) % s.gy, ti = t / (s.gx * s.gy);
+    const int vz = reflect_index(ti * s.ez + z - s.oz, s.D);
+    const int vy = reflect_index(tj * s.ey + y - s.oy, s.H);
+    const int vx = reflect_index(tk * s.ex + x - s.ox, s.W);
+    return s.vol[((size_t)vz * s.H + vy) * s.W + vx];
+}
+
+__global__ void __launch_bounds__(256) conv3_first_kernel(const TileSource s, const float* __restrict__ wk /*[27][Cout]*/,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ out, int Cout, int relu) {
+    const size_t plane = (size_t)s.td * s.th * s.tw;
+    const int local_tile = blockIdx.z;
+    const int cg = blockIdx.y;                       // group of 8 couts
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= plane) return;
+    const int x = (int)(v % s.tw), y = (int)((v / s.tw) % s.th), z = (int)(v / ((size_t)s.tw * s.th));
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+        const float in = tile_voxel(s, local_tile, z + dz, y + dy, x + dx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(in, wk[t * Cout + cg * 8 + j], acc[j]);
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r[j] = acc[j] * scale[cg * 8 + j] + shift[cg * 8 + j];
+        if (relu) r[j] = fmaxf(r[j], 0.0f);
+    }
+    float* o = out + ((size_t)local_tile * plane + v) * Cout + cg * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+}
+
+// MaxPool3d(2) on channels-last: one thread = one output voxel x 4 channels
+__global__ void __launch_bounds__(256) maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       int D, int H, int W, int C, size_t total4) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t v = i / C4;
+        const int x = (int)(v % Wo); v /= Wo;
+        const int y = (int)(v % Ho); v /= Ho;
+        const int z = (int)(v % Do);
+        const size_t tile = v / Do;
+        const float* p = in + (((tile * D + 2 * z) * H + 2 * y) * W + 2 * x) * (size_t)C + 4 * c4;
+        float4 m = *reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(p + ((size_t)((k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1)) * C);
+            m.x = fmaxf(m.x, q.x); m.y = fmaxf(m.y, q.y); m.z = fmaxf(m.z, q.z); m.w = fmaxf(m.w, q.w);
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = m;
+    }
+}
+
+// dc0 (Conv3d 1x1x1, no ReLU, networks.py:66,148) + torch.sigmoid / > 0.5 (segmenter.py:121-124)
+// + the kept-centre crop of Partition.assemble (image_transforms.py:500-503).
+// blocks[tile][class][bz][by][bx], one thread per kept voxel.
+__global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ in, int Cin, int D, int H, int W,
+                                                   int lz, int ly, int lx, int bz, int by, int bx,
+                                                   const float* __restrict__ w /*[ncls][Cin]*/, const float* __restrict__ bias,
+                                                   int ncls, int out_mode, float* __restrict__ blocks) {
+    const size_t nvox = (size_t)bz * by * bx;
+    const int tile = blockIdx.y;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvox) return;
+    const int x = (int)(v % bx), y = (int)((v / bx) % by), z = (int)(v / ((size_t)bx * by));
+    const float* p = in + (((size_t)tile * D + lz + z) * H + ly + y) * (size_t)W * Cin + (size_t)(lx + x) * Cin;
+    float acc[4] = {0, 0, 0, 0};
+    for (int c = 0; c < Cin; c += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p + c);
+        for (int k = 0; k < ncls; ++k) {
+            acc[k] = fmaf(q.x, w[k * Cin + c], acc[k]);
+            acc[k] = fmaf(q.y, w[k * Cin + c + 1], acc[k]);
+            acc[k] = fmaf(q.z, w[k * Cin + c + 2], acc[k]);
+            acc[k] = fmaf(q.w, w[k * Cin + c + 3], acc[k]);
+        }
+    }
+    for (int k = 0; k < ncls; ++k) {
+        float l = acc[k] + bias[k];
+        float r = l;
+        if (out_mode != 2) {
+            const float pr = 1.0f / (1.0f + expf(-l));          // fp32 sigmoid, IEEE divide
+            r = out_mode == 1 ? (pr > 0.5f ? 1.0f : 0.0f) : pr;  // literally sigmoid(x) > 0.5 (SURVEY D-4)
+        }
+        blocks[((size_t)tile * ncls + k) * nvox + v] = r;
+    }
+}
+
+// Partition.assemble: blocks of all tiles -> maps[class][D][H][W] with trim + zeroed frame
+__global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ blocks, int ncls, int D, int H, int W,
+                                                     int ez, int ey, int ex, int gy, int gx, int cz, int cy, int cx,
+                                                     float* __restrict__ maps) {
+    const size_t plane = (size_t)D * H * W;
+    const size_t bvox = (size_t)ez * ey * ex;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane * ncls; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i / plane);
+        const size_t v = i - (size_t)k * plane;
+        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((size_t)W * H));
+        float r = 0.0f;
+        const bool frame = (cz > 0 && (z < cz || z >= D - cz)) || (cy > 0 && (y < cy || y >= H - cy)) ||
+                           (cx > 0 && (x < cx || x >= W - cx));
+        if (!frame) {
+            const int ti = z / ez, tj = y / ey, tk = x / ex;
+            const size_t t = ((size_t)ti * gy + tj) * gx + tk;
+            r = blocks[(t * ncls + k) * bvox + ((size_t)(z - ti * ez) * ey + (y - tj * ey)) * ex + (x - tk * ex)];
+        }
+        maps[i] = r;
+    }
+}
+
+}  // namespace oai

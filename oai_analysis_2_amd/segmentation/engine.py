@@ -1,0 +1,148 @@
+"""Handle over the HIP U-Net (liboai_hip.so): weight ingest from a reference state_dict,
+workspace ownership, and the three launch entry points (tiles / segment / stitch)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+# reference layer order (include/oai_hip.h: OAI_UNET_NUM_LAYERS) and kinds
+LAYER_ORDER = ["ec0", "ec1", "ec2", "ec3", "ec4", "ec5", "ec6", "ec7",
+               "dc9", "dc8", "dc7", "dc6", "dc5", "dc4", "dc3", "dc2", "dc1", "dc0"]
+KIND = {"dc9": 2, "dc6": 2, "dc3": 2, "dc0": 3}
+BN_EPS = 1e-5
+
+
+def _kind(name: str) -> int:
+    if name in KIND:
+        return KIND[name]
+    return 0 if name.startswith("ec") else 1
+
+
+def tile_grid(size_zyx: Sequence[int], tile_zyx: Sequence[int], overlap_zyx: Sequence[int]):
+    """effective size, grid and tile count of Partition (image_transforms.py:407-408), z,y,x order."""
+    eff = [int(t) - 2 * int(o) for t, o in zip(tile_zyx, overlap_zyx)]
+    if min(eff) <= 0:
+        raise ValueError("overlap_size too large for patch_size")
+    grid = [-(-int(s) // e) for s, e in zip(size_zyx, eff)]
+    return eff, grid, grid[0] * grid[1] * grid[2]
+
+
+class UNetEngine:
+    """The reference ``UNet`` (networks.py:38-149) as a resident set of packed weights on the GPU."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device=None, bn_eps: float = BN_EPS):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.OaiError("no HIP device: the MI355X path has no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise _lib.OaiError(f"device {self.device} is not a HIP device: the MI355X path has no CPU fallback")
+        keep = []          # host tensors must outlive oai_unet_create
+
+        def ptr(key):
+            t = state_dict.get(key)
+            if t is None:
+                return None
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        params = (_lib.LayerParams * 18)()
+        known = set()
+        for i, name in enumerate(LAYER_ORDER):
+            wkey = "dc0.weight" if name == "dc0" else f"{name}.0.weight"
+            if wkey not in state_dict:
+                raise KeyError(f"state_dict is missing {wkey} (strict load, utils.py:29)")
+            w = state_dict[wkey]
+            kind = _kind(name)
+            cout, cin = (w.shape[0], w.shape[1]) if kind in (0, 3) else (w.shape[1], w.shape[0])
+            p = params[i]
+            p.kind, p.cin, p.cout = kind, int(cin), int(cout)
+            p.weight = ptr(wkey)
+            if name == "dc0":
+                p.bias = ptr("dc0.bias")
+                known |= {"dc0.weight", "dc0.bias"}
+            else:
+                p.bias = ptr(f"{name}.0.bias")
+                p.bn_gamma, p.bn_beta = ptr(f"{name}.1.weight"), ptr(f"{name}.1.bias")
+                p.bn_mean, p.bn_var = ptr(f"{name}.1.running_mean"), ptr(f"{name}.1.running_var")
+                known |= {f"{name}.0.weight", f"{name}.0.bias", f"{name}.1.weight", f"{name}.1.bias",
+                          f"{name}.1.running_mean", f"{name}.1.running_var", f"{name}.1.num_batches_tracked"}
+        extra = set(state_dict) - known
+        if extra:
+            raise KeyError(f"unexpected keys in state_dict (strict load): {sorted(extra)[:4]}")
+        self.n_classes = int(params[17].cout)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_create(params, C.c_float(bn_eps), C.byref(handle)), "oai_unet_create")
+        self._h = handle
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.oai_unet_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------------------------------
+    def _workspace(self, tile_zyx, batch) -> torch.Tensor:
+        need = int(self.lib.oai_unet_workspace_bytes(self._h, *[int(v) for v in tile_zyx], int(batch)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def tile_flops(self, tile_zyx, overlap_zyx, trimmed: bool) -> float:
+        return float(self.lib.oai_unet_tile_flops(self._h, *[int(v) for v in tile_zyx], _lib.int3(overlap_zyx), int(trimmed)))
+
+    def forward_tiles(self, tiles: torch.Tensor, batch: Optional[int] = None) -> torch.Tensor:
+        """logits[B,n_classes,d,h,w] = model(tiles[B,1,d,h,w]) -- the ``self.model(...)`` of segmenter.py:116."""
+        if tiles.dim() != 5 or tiles.shape[1] != 1:
+            raise ValueError("tiles must be [B,1,D,H,W]")
+        tiles = tiles.to(self.device, torch.float32).contiguous()
+        B, _, d, h, w = tiles.shape
+        ws = self._workspace((d, h, w), min(B, batch or B))
+        out = torch.empty((B, self.n_classes, d, h, w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_forward_tiles(self._h, tiles.data_ptr(), out.data_ptr(), B, d, h, w,
+                                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                       "oai_unet_forward_tiles")
+        return out
+
+    def segment_tiles(self, vol: torch.Tensor, tile_zyx, overlap_zyx, tile_range: Optional[Tuple[int, int]] = None,
+                      out_mode: int = 0, batch: int = 16) -> torch.Tensor:
+        """Kept-centre blocks [n_local, n_classes, ez, ey, ex] of tiles [begin,end) of the volume."""
+        vol = vol.to(self.device, torch.float32).contiguous()
+        D, H, W = vol.shape
+        eff, grid, ntiles = tile_grid((D, H, W), tile_zyx, overlap_zyx)
+        begin, end = tile_range if tile_range is not None else (0, ntiles)
+        batch = max(1, min(int(batch), max(1, end - begin)))
+        ws = self._workspace(tile_zyx, batch)
+        blocks = torch.empty((end - begin, self.n_classes, *eff), dtype=torch.float32, device=self.device)
+        if end > begin:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.oai_segment_tiles(self._h, vol.data_ptr(), D, H, W, _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
+                                                      int(begin), int(end), int(out_mode), blocks.data_ptr(), batch,
+                                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                           "oai_segment_tiles")
+        return blocks
+
+    def stitch(self, blocks: torch.Tensor, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None) -> torch.Tensor:
+        """maps[n_classes, D, H, W] (Partition.assemble, non-vote branch)."""
+        D, H, W = (int(v) for v in size_zyx)
+        eff, grid, ntiles = tile_grid((D, H, W), tile_zyx, overlap_zyx)
+        if blocks.shape[0] != ntiles:
+            raise ValueError(f"stitch needs the blocks of all {ntiles} tiles, got {blocks.shape[0]}")
+        blocks = blocks.contiguous()
+        maps = torch.empty((self.n_classes, D, H, W), dtype=torch.float32, device=self.device)
+        crop = _lib.int3(crop_zyx) if crop_zyx is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_stitch_blocks(blocks.data_ptr(), self.n_classes, D, H, W, _lib.int3(tile_zyx),
+                                                  _lib.int3(overlap_zyx), crop, maps.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "oai_stitch_blocks")
+        return maps

@@ -1,0 +1,87 @@
+"""GPU parity: the HIP U-Net (through the C ABI) vs the oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oai_analysis_2_amd.synth import make_unet_state_dict, make_volume
+from oracle import seg as oseg
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4      # logits gate of SURVEY 8d: max-abs error relative to the tensor's max-abs
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("bn", [False, True])
+def test_forward_tiles_matches_reference_golden(golden_dir, bn):
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z = np.load(os.path.join(golden_dir, "unet_small.npz"))
+    eng = UNetEngine(make_unet_state_dict(seed=int(z["seed"]), bn=bn))
+    got = eng.forward_tiles(torch.from_numpy(z["x"]).cuda()).cpu().numpy()
+    ref = z["logits_bn%d" % int(bn)]
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < REL
+
+
+@pytest.mark.parametrize("width_div,shape", [(4, (8, 16, 24)), (2, (16, 24, 40)), (4, (24, 40, 16))])
+def test_forward_tiles_ragged_shapes_vs_oracle(width_div, shape):
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = make_unet_state_dict(seed=5, width_div=width_div)
+    x = torch.from_numpy(np.stack([make_volume(1, shape), make_volume(2, shape), make_volume(3, shape)]))[:, None]
+    ref = oseg.unet_forward(x, sd).numpy()
+    got = UNetEngine(sd).forward_tiles(x.cuda()).cpu().numpy()
+    assert _rel(got, ref) < REL
+
+
+def test_full_size_tile_matches_reference_golden(golden_dir):
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z = np.load(os.path.join(golden_dir, "unet_fulltile.npz"))
+    vol = make_volume(int(z["volume_seed"]), (32, 128, 128))
+    sd = make_unet_state_dict(seed=int(z["weight_seed"]))
+    eng = UNetEngine(sd)
+    got = eng.forward_tiles(torch.from_numpy(vol)[None, None].cuda()).cpu().numpy()[0]
+    ref = z["logits_centre"]
+    err = np.abs(got[:, 8:24, 16:112, 16:112] - ref).max() / float(z["logits_abs_max"])
+    assert err < REL
+    # the trimmed, gather-fused segment path on a one-tile volume vs the oracle on the same tile
+    centre = np.ascontiguousarray(vol[8:24, 16:112, 16:112])
+    blocks = eng.segment_tiles(torch.from_numpy(centre).cuda(), (32, 128, 128), (8, 16, 16), out_mode=2).cpu().numpy()
+    tiles, g = oseg.partition(centre, (128, 128, 32), (16, 16, 8))
+    assert tiles.shape[0] == 1
+    ref2 = oseg.unet_forward(torch.from_numpy(tiles), sd).numpy()[:, :, 8:24, 16:112, 16:112]
+    assert blocks.shape == ref2.shape
+    assert _rel(blocks, ref2) < REL
+
+
+def test_segment_small_matches_reference_golden(golden_dir):
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z = np.load(os.path.join(golden_dir, "segment_small.npz"))
+    vol = make_volume(int(z["volume_seed"]), (24, 72, 72))
+    patch, ovl = tuple(int(v) for v in z["patch"]), tuple(int(v) for v in z["overlap"])
+    tile_zyx, ovl_zyx = patch[::-1], ovl[::-1]
+    eng = UNetEngine(make_unet_state_dict(seed=int(z["weight_seed"])))
+    v = torch.from_numpy(vol).cuda()
+    crop_zyx = (ovl[2], ovl[0], ovl[1])             # assemble indexes crop_size as (x,y,z): image_transforms.py:511-512
+    blocks = eng.segment_tiles(v, tile_zyx, ovl_zyx, out_mode=0, batch=7)    # ragged last batch
+    maps = eng.stitch(blocks, vol.shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy().astype(np.float64)
+    # the reference's own acceptance test: sum|d| < 12 per 23.6M voxels (test/test_all.py:32-33)
+    budget = 12.0 * vol.size / 23592960
+    assert np.abs(maps[0] - z["fc_prob"]).sum() < budget
+    assert np.abs(maps[1] - z["tc_prob"]).sum() < budget
+    assert np.abs(maps[0] - z["fc_prob"]).max() < 1e-5
+    # masks: sigmoid(x) > 0.5, identical except where the reference prob is within fp32 noise of 0.5
+    mblocks = eng.segment_tiles(v, tile_zyx, ovl_zyx, out_mode=1, batch=16)
+    masks = eng.stitch(mblocks, vol.shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
+    for got, ref, prob in ((masks[0], z["fc_mask"], z["fc_prob"]), (masks[1], z["tc_mask"], z["tc_prob"])):
+        diff = got.astype(np.uint8) != ref
+        assert diff.sum() <= 3, f"{diff.sum()} mask voxels differ"
+        assert np.all(np.abs(prob[diff] - 0.5) < 1e-5)
+    # tile-range sharding (the multi-GPU path) produces the same blocks
+    part = torch.cat([eng.segment_tiles(v, tile_zyx, ovl_zyx, (0, 30), 0, 8), eng.segment_tiles(v, tile_zyx, ovl_zyx, (30, 75), 0, 8)])
+    assert torch.equal(part, blocks)
