@@ -1,0 +1,357 @@
+// ICON gradICON registration network on gfx950: three tallUNet2s + the warp/compose chain of
+// TwoStep(Downsample(TwoStep(FFVF(u1),FFVF(u2))), FFVF(u3)).  Restates icon_registration 1.1.2
+// (see oracle/icon.py; reference call sites oai_analysis/registration.py:20,25).
+//
+// The nets are 0.1 TFLOP per direction against 80-156 TFLOP for the segmentation U-Net, with
+// channel counts (2,16,18,48,3) that do not fill an MFMA tile, so they run as direct fp32 VALU
+// convolutions: one thread = one output voxel x COUT_T couts held in registers, lanes along x
+// (coalesced NCDHW reads), weights repacked [ci][tap][co] so the COUT_T weights of a step are one
+// wave-uniform scalar load (s_load_dwordxN feeding v_fma with an SGPR operand: no LDS, no barrier).
+// torch.cat is free: every tensor is produced directly into its channel slice of the level's
+// concat buffer  cat_d = [ up_out[d] | down[d] ]  (UNet2.forward: x = cat([x, skips[d]], 1)).
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kDown[6] = {2, 16, 32, 64, 256, 512};
+constexpr int kUpOut[5] = {16, 32, 64, 128, 256};
+constexpr int kUpIn[5] = {48, 96, 192, 512, 512};
+constexpr float kLeaky = 0.01f;
+constexpr float kBnEps = 1e-5f;
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : v * kLeaky; }
+
+// Conv3d k3 p1, stride S, on leaky_relu(x) (PRE) + bias, optional residual
+//   RES: + avg_pool3d(x,2,ceil_mode=True) zero-padded IN FRONT to Cout channels (UNet2 down path)
+// out = (acc + bias [+ res]) / div
+template <int S, int COUT_T, bool PRE, bool RES>
+__global__ void __launch_bounds__(256)
+icon_conv3_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
+                  const float* __restrict__ wk /*[Cin][27][Cout]*/, const float* __restrict__ bias,
+                  float* __restrict__ out, int Cout, int Do, int Ho, int Wo, float div) {
+    const int cg = blockIdx.y;
+    const long long nvox = (long long)Do * Ho * Wo;
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvox) return;
+    const int ox = (int)(v % Wo), oy = (int)((v / Wo) % Ho), oz = (int)(v / ((long long)Wo * Ho));
+    const long long plane = (long long)D * H * W;
+    float acc[COUT_T];
+#pragma unroll
+    for (int j = 0; j < COUT_T; ++j) acc[j] = 0.0f;
+    const int iz0 = oz * S - 1, iy0 = oy * S - 1, ix0 = ox * S - 1;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xp = x + ci * plane;
+        const float* wp = wk + ((long long)ci * 27) * Cout + cg * COUT_T;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int iz = iz0 + t / 9, iy = iy0 + (t / 3) % 3, ix = ix0 + t % 3;
+            float in = 0.0f;
+            if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                in = xp[((long long)iz * H + iy) * W + ix];
+            if (PRE) in = leaky(in);
+#pragma unroll
+            for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(in, wp[t * Cout + j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < COUT_T; ++j) {
+        const int co = cg * COUT_T + j;
+        float r = acc[j] + bias[co];
+        if (RES) {
+            const int cs = co - (Cout - Cin);          // pad_or_crop pads zero channels in front
+            if (cs >= 0) {
+                const int z1 = min(2 * oz + 2, D), y1 = min(2 * oy + 2, H), x1 = min(2 * ox + 2, W);
+                float s = 0.0f;
+                for (int z = 2 * oz; z < z1; ++z)
+                    for (int y = 2 * oy; y < y1; ++y)
+                        for (int xx = 2 * ox; xx < x1; ++xx) s += x[cs * plane + ((long long)z * H + y) * W + xx];
+                r += s / (float)((z1 - 2 * oz) * (y1 - 2 * oy) * (x1 - 2 * ox));
+            }
+        }
+        out[co * nvox + v] = div == 1.0f ? r : r / div;
+    }
+}
+
+__device__ __forceinline__ void up_src(int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    // F.interpolate(scale_factor=2, mode='trilinear', align_corners=False): src = (dst + 0.5)/2 - 0.5, clamped at 0
+    float src = 0.5f * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+// ConvTranspose3d k4 s2 p1 on leaky_relu(x) + bias + trilinear-x2 upsample of x[:Cout] -> BatchNorm (eval)
+// -> cropped to (Dc,Hc,Wc).  One block = one output parity class (uniform weights).
+template <int COUT_T>
+__global__ void __launch_bounds__(256)
+icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
+               const float* __restrict__ wk /*[Cin][64][Cout]*/, const float* __restrict__ bias,
+               const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+               float* __restrict__ out, int Cout, int Dc, int Hc, int Wc) {
+    const int cg = blockIdx.y;
+    const int par = blockIdx.z, pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+    const int nz = (Dc - pz + 1) / 2, ny = (Hc - py + 1) / 2, nx = (Wc - px + 1) / 2;
+    const long long nv = (long long)nz * ny * nx;
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const int tx = (int)(v % nx), ty = (int)((v / nx) % ny), tz = (int)(v / ((long long)nx * ny));
+    const int oz = 2 * tz + pz, oy = 2 * ty + py, ox = 2 * tx + px;
+    const long long plane = (long long)D * H * W;
+    const long long oplane = (long long)Dc * Hc * Wc;
+    // o = 2 i - 1 + k  ->  k in {q, q+2}, q = (p+1)&1;  i = (o + 1 - k)/2
+    const int qz = (pz + 1) & 1, qy = (py + 1) & 1, qx = (px + 1) & 1;
+    float acc[COUT_T];
+#pragma unroll
+    for (int j = 0; j < COUT_T; ++j) acc[j] = 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xp = x + ci * plane;
+        const float* wp = wk + ((long long)ci * 64) * Cout + cg * COUT_T;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int kz = qz + 2 * (t >> 2), ky = qy + 2 * ((t >> 1) & 1), kx = qx + 2 * (t & 1);
+            const int iz = (oz + 1 - kz) >> 1, iy = (oy + 1 - ky) >> 1, ix = (ox + 1 - kx) >> 1;
+            float in = 0.0f;
+            if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                in = leaky(xp[((long long)iz * H + iy) * W + ix]);
+            const float* w = wp + ((kz * 4 + ky) * 4 + kx) * Cout;
+#pragma unroll
+            for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(in, w[j], acc[j]);
+        }
+    }
+    int z0, z1, y0, y1, x0, x1;
+    float a0, a1, b0, b1, c0, c1;
+    up_src(oz, D, z0, z1, a0, a1);
+    up_src(oy, H, y0, y1, b0, b1);
+    up_src(ox, W, x0, x1, c0, c1);
+#pragma unroll
+    for (int j = 0; j < COUT_T; ++j) {
+        const int co = cg * COUT_T + j;
+        const float* p = x + co * plane;          // pad_or_crop(x, Cout): the first Cout channels (Cin >= Cout)
+        auto at = [&](int zz, int yy, int xx) { return p[((long long)zz * H + yy) * W + xx]; };
+        const float res = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
+                          a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
+        const float r = (acc[j] + bias[co]) + res;
+        out[co * oplane + ((long long)oz * Hc + oy) * Wc + ox] = r * bn_scale[co] + bn_shift[co];
+    }
+}
+
+struct NetWeights {
+    float* down_w[5]; float* down_b[5];
+    float* up_w[5]; float* up_b[5]; float* bn_s[5]; float* bn_t[5];
+    float* last_w; float* last_b;
+};
+
+}  // namespace
+
+struct oai_icon {
+    NetWeights net[3];
+    int D, H, W;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+int upload(oai_icon* h, const std::vector<float>& v, float** dst) {
+    void* d = nullptr;
+    OAI_CHECK_HIP(hipMalloc(&d, v.size() * sizeof(float)));
+    h->allocs.push_back(d);
+    OAI_CHECK_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dst = (float*)d;
+    return OAI_OK;
+}
+
+// Conv3d [Co][Ci][27] -> [Ci][27][Co]
+std::vector<float> repack_conv(const float* w, int co_n, int ci_n, int taps) {
+    std::vector<float> o((size_t)co_n * ci_n * taps);
+    for (int co = 0; co < co_n; ++co)
+        for (int ci = 0; ci < ci_n; ++ci)
+            for (int t = 0; t < taps; ++t) o[((size_t)ci * taps + t) * co_n + co] = w[((size_t)co * ci_n + ci) * taps + t];
+    return o;
+}
+// ConvTranspose3d [Ci][Co][64] -> [Ci][64][Co]
+std::vector<float> repack_convT(const float* w, int ci_n, int co_n, int taps) {
+    std::vector<float> o((size_t)co_n * ci_n * taps);
+    for (int ci = 0; ci < ci_n; ++ci)
+        for (int co = 0; co < co_n; ++co)
+            for (int t = 0; t < taps; ++t) o[((size_t)ci * taps + t) * co_n + co] = w[((size_t)ci * co_n + co) * taps + t];
+    return o;
+}
+
+struct Dims { int d[6][3]; long long vox[6]; };
+
+Dims level_dims(int D, int H, int W) {
+    Dims r;
+    r.d[0][0] = D; r.d[0][1] = H; r.d[0][2] = W;
+    for (int l = 1; l < 6; ++l) for (int i = 0; i < 3; ++i) r.d[l][i] = (r.d[l - 1][i] + 1) / 2;
+    for (int l = 0; l < 6; ++l) r.vox[l] = (long long)r.d[l][0] * r.d[l][1] * r.d[l][2];
+    return r;
+}
+
+size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+// floats needed by one tallUNet2 forward at (D,H,W): cat_0..cat_4 and the bottom tensor
+size_t unet_ws_floats(int D, int H, int W) {
+    const Dims dm = level_dims(D, H, W);
+    size_t n = 0;
+    for (int l = 0; l < 5; ++l) n += align256((size_t)(kUpOut[l] + kDown[l]) * dm.vox[l] * 4) / 4;
+    n += align256((size_t)kDown[5] * dm.vox[5] * 4) / 4;
+    return n;
+}
+
+int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, int H, int W, float* out,
+                 float* ws, hipStream_t st) {
+    const Dims dm = level_dims(D, H, W);
+    // every axis must survive five halvings with a >= 2 input to each pooling (avg_pool3d needs size >= kernel)
+    float* cat[5];
+    size_t o = 0;
+    for (int l = 0; l < 5; ++l) { cat[l] = ws + o; o += align256((size_t)(kUpOut[l] + kDown[l]) * dm.vox[l] * 4) / 4; }
+    float* bottom = ws + o;
+    // x = cat([a, b], 1) lives in the skip slice of cat_0
+    OAI_CHECK_HIP(hipMemcpyAsync(cat[0] + (size_t)kUpOut[0] * dm.vox[0], a, dm.vox[0] * 4, hipMemcpyDeviceToDevice, st));
+    OAI_CHECK_HIP(hipMemcpyAsync(cat[0] + (size_t)(kUpOut[0] + 1) * dm.vox[0], b, dm.vox[0] * 4, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < 5; ++l) {
+        const float* src = cat[l] + (size_t)kUpOut[l] * dm.vox[l];
+        float* dst = l < 4 ? cat[l + 1] + (size_t)kUpOut[l + 1] * dm.vox[l + 1] : bottom;
+        dim3 grid(oai::cdiv(dm.vox[l + 1], 256), kDown[l + 1] / 16);
+        icon_conv3_kernel<2, 16, true, true><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
+                                                                    nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
+                                                                    dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+        OAI_CHECK_LAUNCH();
+    }
+    for (int l = 4; l >= 0; --l) {
+        const float* src = l == 4 ? bottom : cat[l + 1];
+        const long long per_par = (long long)((dm.d[l][0] + 1) / 2) * ((dm.d[l][1] + 1) / 2) * ((dm.d[l][2] + 1) / 2);
+        dim3 grid(oai::cdiv(per_par, 256), kUpOut[l] / 16, 8);
+        icon_up_kernel<16><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                  nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                  dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        OAI_CHECK_LAUNCH();
+    }
+    dim3 grid(oai::cdiv(dm.vox[0], 256), 1);
+    icon_conv3_kernel<1, 3, false, false><<<grid, 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W, nw.last_w, nw.last_b,
+                                                                 out, 3, D, H, W, 10.0f);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+bool dims_ok(int D, int H, int W) {
+    const Dims dm = level_dims(D, H, W);
+    for (int i = 0; i < 3; ++i)
+        if (dm.d[4][i] < 2) return false;     // the 5th avg_pool3d(2) needs an input of at least 2 per axis
+    return true;
+}
+
+struct Ws {
+    float *a, *b, *d1, *d2, *d3, *aw, *c1, *c2, *Aw, *unet;
+    size_t total_bytes;
+};
+
+Ws plan_ws(int D, int H, int W, char* base) {
+    const long long vh = (long long)D * H * W;
+    const int d = (D + 1) / 2, h = (H + 1) / 2, w = (W + 1) / 2;
+    const long long vl = (long long)d * h * w;
+    size_t o = 0;
+    auto take = [&](size_t floats) { float* p = (float*)(base + o); o += align256(floats * 4); return p; };
+    Ws s;
+    s.a = take(vl); s.b = take(vl); s.d1 = take(3 * vl); s.d2 = take(3 * vl); s.aw = take(vl);
+    s.d3 = take(3 * vh); s.c1 = take(3 * vh); s.c2 = take(3 * vh); s.Aw = take(vh);
+    s.unet = take(unet_ws_floats(D, H, W));
+    s.total_bytes = o;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oai_icon_create(const oai_icon_unet_params nets[3], int D, int H, int W, oai_icon** out) {
+    OAI_CHECK_ARG(nets && out, "oai_icon_create: null pointer");
+    OAI_CHECK_ARG(dims_ok((D + 1) / 2, (H + 1) / 2, (W + 1) / 2),
+                  "oai_icon_create: network shape %dx%dx%d too small (each low-resolution axis must be >= 17)", D, H, W);
+    oai_icon* h = new oai_icon();
+    h->D = D; h->H = H; h->W = W;
+    int rc = OAI_OK;
+    for (int n = 0; n < 3 && rc == OAI_OK; ++n) {
+        const oai_icon_unet_params& p = nets[n];
+        NetWeights& nw = h->net[n];
+        for (int l = 0; l < 5 && rc == OAI_OK; ++l) {
+            if (!p.down_w[l] || !p.down_b[l] || !p.up_w[l] || !p.up_b[l] || !p.bn_gamma[l] || !p.bn_beta[l] || !p.bn_mean[l] || !p.bn_var[l]) {
+                rc = oai::set_error(OAI_ERR_ARG, "oai_icon_create: net %d level %d has a null parameter", n, l);
+                break;
+            }
+            if ((rc = upload(h, repack_conv(p.down_w[l], kDown[l + 1], kDown[l], 27), &nw.down_w[l]))) break;
+            if ((rc = upload(h, std::vector<float>(p.down_b[l], p.down_b[l] + kDown[l + 1]), &nw.down_b[l]))) break;
+            if ((rc = upload(h, repack_convT(p.up_w[l], kUpIn[l], kUpOut[l], 64), &nw.up_w[l]))) break;
+            if ((rc = upload(h, std::vector<float>(p.up_b[l], p.up_b[l] + kUpOut[l]), &nw.up_b[l]))) break;
+            std::vector<float> s(kUpOut[l]), t(kUpOut[l]);
+            for (int c = 0; c < kUpOut[l]; ++c) {
+                s[c] = p.bn_gamma[l][c] / sqrtf(p.bn_var[l][c] + kBnEps);
+                t[c] = p.bn_beta[l][c] - p.bn_mean[l][c] * s[c];
+            }
+            if ((rc = upload(h, s, &nw.bn_s[l]))) break;
+            if ((rc = upload(h, t, &nw.bn_t[l]))) break;
+        }
+        if (rc) break;
+        if (!p.last_w || !p.last_b) { rc = oai::set_error(OAI_ERR_ARG, "oai_icon_create: net %d lastConv is null", n); break; }
+        if ((rc = upload(h, repack_conv(p.last_w, 3, 18, 27), &nw.last_w))) break;
+        if ((rc = upload(h, std::vector<float>(p.last_b, p.last_b + 3), &nw.last_b))) break;
+    }
+    if (rc) { oai_icon_destroy(h); return rc; }
+    *out = h;
+    return OAI_OK;
+}
+
+void oai_icon_destroy(oai_icon* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+size_t oai_icon_workspace_bytes(const oai_icon* h) {
+    if (!h) return 0;
+    return plan_ws(h->D, h->H, h->W, nullptr).total_bytes;
+}
+
+int oai_icon_unet_forward(oai_icon* h, int which, const float* a, const float* b, int D, int H, int W, float* out,
+                          void* ws, size_t ws_bytes, void* stream) {
+    OAI_CHECK_ARG(h && a && b && out && ws, "oai_icon_unet_forward: null pointer");
+    OAI_CHECK_ARG(which >= 0 && which < 3, "oai_icon_unet_forward: net index must be 0..2");
+    OAI_CHECK_ARG(dims_ok(D, H, W), "oai_icon_unet_forward: %dx%dx%d too small for five 2x poolings (each axis >= 17)", D, H, W);
+    if (unet_ws_floats(D, H, W) * 4 > ws_bytes)
+        return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_unet_forward: workspace %zu B < %zu B", ws_bytes, unet_ws_floats(D, H, W) * 4);
+    return unet_forward(h->net[which], a, b, D, H, W, out, (float*)ws, (hipStream_t)stream);
+}
+
+int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, void* ws, size_t ws_bytes, void* stream) {
+    OAI_CHECK_ARG(h && A && B && phi && ws, "oai_icon_forward: null pointer");
+    const int D = h->D, H = h->H, W = h->W;
+    const int d = (D + 1) / 2, hh = (H + 1) / 2, w = (W + 1) / 2;
+    Ws s = plan_ws(D, H, W, (char*)ws);
+    if (s.total_bytes > ws_bytes)
+        return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_forward: workspace %zu B < %zu B", ws_bytes, s.total_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+#define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
+    RUN(oai_avgpool2_3d(A, 1, D, H, W, s.a, st));                                  // DownsampleRegistration.forward
+    RUN(oai_avgpool2_3d(B, 1, D, H, W, s.b, st));
+    RUN(unet_forward(h->net[0], s.a, s.b, d, hh, w, s.d1, s.unet, st));            // FFVF(u1)
+    RUN(oai_compose(s.d1, d, hh, w, nullptr, d, hh, w, 1, s.c1, st));              // id_l + d1 (isIdentity shortcut)
+    RUN(oai_grid_sample3d(s.a, 1, d, hh, w, s.c1, d, hh, w, s.aw, st));            // a warped
+    RUN(unet_forward(h->net[1], s.aw, s.b, d, hh, w, s.d2, s.unet, st));           // FFVF(u2)
+    RUN(oai_compose(s.d2, d, hh, w, nullptr, D, H, W, 0, s.c1, st));               // c1 = id_h + sample(d2, id_h)
+    RUN(oai_compose(s.d1, d, hh, w, s.c1, D, H, W, 0, s.c2, st));                  // c2 = c1 + sample(d1, c1)
+    RUN(oai_grid_sample3d(A, 1, D, H, W, s.c2, D, H, W, s.Aw, st));                // A warped
+    RUN(unet_forward(h->net[2], s.Aw, B, D, H, W, s.d3, s.unet, st));              // FFVF(u3)
+    RUN(oai_compose(s.d3, D, H, W, nullptr, D, H, W, 1, s.c1, st));                // c3 = id_h + d3 (shortcut)
+    RUN(oai_compose(s.d2, d, hh, w, s.c1, D, H, W, 0, s.c2, st));                  // c4 = c3 + sample(d2, c3)
+    RUN(oai_compose(s.d1, d, hh, w, s.c2, D, H, W, 0, phi, st));                   // phi = c4 + sample(d1, c4)
+#undef RUN
+    return OAI_OK;
+}
+
+}  // extern "C"

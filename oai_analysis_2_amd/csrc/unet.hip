@@ -113,6 +113,7 @@ static void plan_regions(const int tile[3], const int keep_lo[3], const int keep
     int dims[4][3];
     for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) dims[l][i] = tile[i] >> l;
     for (int k = 0; k < 18; ++k) full_box(need[k], dims[kLevel[k]]);
+    for (int i = 0; i < 3; ++i) { need[DC0].lo[i] = keep_lo[i]; need[DC0].hi[i] = keep_hi[i]; }   // the head always crops
     if (!trimmed) return;
     auto grow = [&](const Box& b, int lvl) { Box r; for (int i = 0; i < 3; ++i) { r.lo[i] = b.lo[i] > 0 ? b.lo[i] - 1 : 0; r.hi[i] = b.hi[i] + 1 < dims[lvl][i] ? b.hi[i] + 1 : dims[lvl][i]; } return r; };
     auto halve = [&](const Box& b) { Box r; for (int i = 0; i < 3; ++i) { r.lo[i] = b.lo[i] / 2; r.hi[i] = (b.hi[i] + 1) / 2; } return r; };

@@ -87,3 +87,136 @@ class DisplacementTransform:
         comp.PrependTransform(tr)
         comp.PrependTransform(affine(self.image_A))
         return comp
+
+
+# --------------------------------------------------------------------------------------------------
+# engine: three tallUNet2s resident on the GPU + the warp/compose chain, all in liboai_hip.so
+
+_NET_PREFIXES = ("netPhi.net.netPhi.net.", "netPhi.net.netPsi.net.", "netPsi.net.")   # u1, u2 (low-res), u3
+
+
+class IconEngine:
+    """``OAI_knees_gradICON_model().regis_net`` as packed weights + HIP kernels."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], net_shape: Sequence[int] = NET_SHAPE, device=None):
+        import ctypes as C
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.OaiError("no HIP device: the MI355X path has no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.net_shape = tuple(int(v) for v in net_shape)
+        keep = []
+
+        def ptr(key):
+            if key not in state_dict:
+                raise KeyError(f"ICON state_dict is missing {key}")
+            t = state_dict[key].detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        params = (_lib.IconUnetParams * 3)()
+        for n, pre in enumerate(_NET_PREFIXES):
+            p = params[n]
+            for d in range(5):
+                p.down_w[d], p.down_b[d] = ptr(f"{pre}downConvs.{d}.weight"), ptr(f"{pre}downConvs.{d}.bias")
+                p.up_w[d], p.up_b[d] = ptr(f"{pre}upConvs.{d}.weight"), ptr(f"{pre}upConvs.{d}.bias")
+                p.bn_gamma[d], p.bn_beta[d] = ptr(f"{pre}batchNorms.{d}.weight"), ptr(f"{pre}batchNorms.{d}.bias")
+                p.bn_mean[d], p.bn_var[d] = ptr(f"{pre}batchNorms.{d}.running_mean"), ptr(f"{pre}batchNorms.{d}.running_var")
+            p.last_w, p.last_b = ptr(f"{pre}lastConv.weight"), ptr(f"{pre}lastConv.bias")
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_icon_create(params, *self.net_shape, C.byref(handle)), "oai_icon_create")
+        self._h = handle
+        self._ws = torch.empty(int(self.lib.oai_icon_workspace_bytes(self._h)), dtype=torch.uint8, device=self.device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.oai_icon_destroy(h)
+            self._h = None
+
+    def unet(self, which: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """One tallUNet2: a, b [D,H,W] -> displacement [3,D,H,W] (unit-test seam)."""
+        a = a.to(self.device, torch.float32).contiguous()
+        b = b.to(self.device, torch.float32).contiguous()
+        D, H, W = a.shape
+        out = torch.empty((3, D, H, W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_icon_unet_forward(self._h, which, a.data_ptr(), b.data_ptr(), D, H, W, out.data_ptr(),
+                                                      self._ws.data_ptr(), self._ws.numel(),
+                                                      torch.cuda.current_stream().cuda_stream), "oai_icon_unet_forward")
+        return out
+
+    def phi(self, A_net: torch.Tensor, B_net: torch.Tensor) -> torch.Tensor:
+        """phi_AB(identity) [3,D,H,W] for network-resolution images (one direction of GradientICON.forward)."""
+        A_net = A_net.to(self.device, torch.float32).contiguous()
+        B_net = B_net.to(self.device, torch.float32).contiguous()
+        if tuple(A_net.shape) != self.net_shape or tuple(B_net.shape) != self.net_shape:
+            raise ValueError(f"images must be resized to the network shape {self.net_shape}")
+        out = torch.empty((3, *self.net_shape), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_icon_forward(self._h, A_net.data_ptr(), B_net.data_ptr(), out.data_ptr(),
+                                                 self._ws.data_ptr(), self._ws.numel(),
+                                                 torch.cuda.current_stream().cuda_stream), "oai_icon_forward")
+        return out
+
+    def register_pair(self, image_A: torch.Tensor, image_B: torch.Tensor, both: bool = False):
+        """``itk_wrapper.register_pair`` on device tensors [z,y,x]: resize -> net -> dense phi (AB[, BA])."""
+        A = ops.resize_trilinear(image_A.to(self.device, torch.float32)[None], self.net_shape)[0]
+        B = ops.resize_trilinear(image_B.to(self.device, torch.float32)[None], self.net_shape)[0]
+        phi_AB = self.phi(A, B)
+        phi_BA = self.phi(B, A) if both else None
+        return phi_AB, phi_BA
+
+
+class ICON_Registration:
+    """Drop-in for oai_analysis.registration.ICON_Registration (registration.py:18-27).
+
+    ``weights``: a ``regis_net`` state_dict, a path to one (``torch.load``), or None to read
+    ``$OAI_DATA_DIR/icon_weights.pth`` (the reference downloads them; there is no network here).
+    """
+
+    def __init__(self, weights=None, net_shape: Sequence[int] = NET_SHAPE, device=None, verbose: bool = True):
+        import os
+        if weights is None:
+            root = os.environ.get("OAI_DATA_DIR")
+            if not root:
+                raise ValueError("ICON weights needed: pass weights= or set OAI_DATA_DIR (no network download here)")
+            weights = os.path.join(root, "icon_weights.pth")
+        if isinstance(weights, (str, os.PathLike)):
+            if not os.path.isfile(weights):
+                raise ValueError(f"=> no checkpoint found at '{weights}'")
+            weights = torch.load(weights, map_location="cpu")
+        self.register_module = IconEngine(weights, net_shape, device)
+        self.verbose = verbose
+
+    def register(self, fixed_image, moving_image) -> DisplacementTransform:
+        fixed, moving = as_image(fixed_image), as_image(moving_image)
+        if self.verbose:
+            print("fixed range", np.min(fixed.array), np.max(fixed.array))          # registration.py:23-24
+            print("moving range", np.min(moving.array), np.max(moving.array))
+        if np.max(fixed.array) == np.min(fixed.array) or np.max(moving.array) == np.min(moving.array):
+            raise AssertionError("constant image")                                   # register_pair's asserts
+        eng = self.register_module
+        A = torch.from_numpy(np.ascontiguousarray(fixed.array, dtype=np.float32)).to(eng.device)
+        B = torch.from_numpy(np.ascontiguousarray(moving.array, dtype=np.float32)).to(eng.device)
+        phi_AB, _ = eng.register_pair(A, B, both=False)
+        disp = ops.phi_to_itk_displacement(phi_AB)
+        return DisplacementTransform(disp.cpu().numpy(), _meta_only(fixed), _meta_only(moving), phi_AB.cpu().numpy())
+
+
+def _meta_only(img: Image) -> Image:
+    """Geometry of ``img`` with a zero-stride placeholder array of the same shape (no voxel copy)."""
+    arr = np.broadcast_to(np.zeros((), dtype=np.float32), img.array.shape)
+    return Image(arr, img.spacing.copy(), img.origin.copy(), img.direction.copy())
+
+
+def deform_probmap(phi_AB: DisplacementTransform, image_A, image_B, prob_map, device=None) -> Image:
+    """The reference's ``deform_probmap`` helper (test/test_all.py:42-52, dask_processing.py:95-111) on the GPU."""
+    A, B, P = as_image(image_A), as_image(image_B), as_image(prob_map)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    disp = torch.from_numpy(np.ascontiguousarray(phi_AB.displacement)).to(dev)
+    prob = torch.from_numpy(np.ascontiguousarray(P.array, dtype=np.float32)).to(dev)
+    b2n, n2a = resample_affines(A, B, phi_AB.net_shape)
+    out = ops.resample_through_disp(prob, disp, b2n, n2a, B.array.shape)
+    return B.like(out.cpu().numpy().astype(np.float64))

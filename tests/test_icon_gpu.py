@@ -1,0 +1,57 @@
+"""GPU parity: ICON network + warp chain (through the C ABI) vs the oracle (oracle/icon.py).
+
+The oracle for this part is PARITY UNPINNED (icon_registration is absent from the reference tree and
+this image); these tests prove the HIP path equals the restatement, at the north-star tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from oai_analysis_2_amd.synth import make_icon_state_dict, make_volume
+from oracle import icon as oicon
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(20, 24, 24), (17, 33, 21), (40, 48, 48)])
+def test_tall_unet2(shape):
+    from oai_analysis_2_amd.registration import IconEngine
+    sd = make_icon_state_dict(1)
+    eng = IconEngine(sd, net_shape=(40, 48, 48))
+    a, b = make_volume(1, shape), make_volume(2, shape)
+    for which, pre in enumerate((oicon.U1, oicon.U2, oicon.U3)):
+        ref = oicon.tall_unet2(torch.from_numpy(a)[None, None], torch.from_numpy(b)[None, None], sd, pre)[0].numpy()
+        got = eng.unet(which, torch.from_numpy(a), torch.from_numpy(b)).cpu().numpy()
+        assert got.shape == ref.shape
+        assert _rel(got, ref) < TOL, (which, _rel(got, ref))
+
+
+def test_phi_small_and_register_pair():
+    from oai_analysis_2_amd.registration import IconEngine
+    sd = make_icon_state_dict(2)
+    net = (40, 48, 48)
+    eng = IconEngine(sd, net_shape=net)
+    A, B = make_volume(3, (50, 90, 96)), make_volume(4, (44, 100, 88))
+    ref_AB, ref_BA = oicon.register_pair_arrays(A, B, sd, net_shape=net, both=True)
+    got_AB, got_BA = eng.register_pair(torch.from_numpy(A), torch.from_numpy(B), both=True)
+    ident = oicon.identity_map(net)[0].numpy()
+    for got, ref in ((got_AB, ref_AB), (got_BA, ref_BA)):
+        got, ref = got.cpu().numpy(), ref[0].numpy()
+        assert np.abs(ref - ident).max() > 0.01            # a real deformation, not the identity
+        assert _rel(got - ident, ref - ident) < TOL        # displacement field within 1e-4 rel (north star)
+
+
+def test_phi_full_resolution_80x192x192():
+    from oai_analysis_2_amd.registration import IconEngine
+    sd = make_icon_state_dict(0)
+    eng = IconEngine(sd)
+    A, B = make_volume(5, (80, 192, 192)), make_volume(6, (80, 192, 192))
+    ref = oicon.regis_net_direction(torch.from_numpy(A)[None, None], torch.from_numpy(B)[None, None], sd)[0].numpy()
+    got = eng.phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy()
+    ident = oicon.identity_map((80, 192, 192))[0].numpy()
+    assert _rel(got - ident, ref - ident) < TOL
