@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""bench.py -- knee MRI volumes/s (segment + register + FC/TC resample), 384x384x160 fp32.
+
+One "step" = one synthetic DESS volume through the whole per-volume hot path on one GPU:
+overlap-tiled 3D U-Net segmentation (160 tiles of 128x128x32, reference tiling) -> stitch -> ICON
+registration to the atlas (one direction, what ICON_Registration.register returns) -> both probability
+maps pulled onto the atlas grid through phi.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, volumes are independent units (the reference's own Dask model), every rank
+processes its own volume per step, no data-path collective ("scaling": "weak").  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VOL_SHAPE = (160, 384, 384)
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+
+
+def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
+    """The oracle (CPU port of the reference algorithm) timed on this host, on a bounded sample."""
+    from oai_analysis_2_amd.image import Image
+    from oracle import icon as oicon, resample as oresample, seg as oseg
+    threads = torch.get_num_threads()
+    tiles, g = oseg.partition(vol_np, (128, 128, 32), (16, 16, 8))
+    x = torch.from_numpy(np.ascontiguousarray(tiles[:n_tiles_sample]))
+    oseg.unet_forward(x[:1], unet_sd)                                    # warm-up
+    t0 = time.time()
+    for i in range(n_tiles_sample):
+        oseg.unet_forward(x[i:i + 1], unet_sd)
+    t_tile = (time.time() - t0) / n_tiles_sample
+    t0 = time.time()
+    phi, _ = oicon.register_pair_arrays(vol_np, atlas_img.array, icon_sd, both=False)
+    t_reg = time.time() - t0
+    disp = oicon.displacement_itk(phi)
+    t0 = time.time()
+    zs = 16                                                               # 16 of 160 atlas slices, scaled x10
+    sub = Image(atlas_img.array[:zs], atlas_img.spacing, atlas_img.origin, atlas_img.direction)
+    oresample.resample_through_phi(vol_np.astype(np.float64), disp, meta_A, sub)
+    t_res = (time.time() - t0) * (atlas_img.array.shape[0] / zs) * 2      # FC and TC
+    t_vol = g["n_tiles"] * t_tile + t_reg + t_res
+    return {"value": 1.0 / t_vol, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"{n_tiles_sample} of {g['n_tiles']} U-Net tiles (x{g['n_tiles'] / n_tiles_sample:.0f}), "
+                      f"1 full ICON direction, {zs}/{atlas_img.array.shape[0]} slices of one resample (x{2 * atlas_img.array.shape[0] // zs}); "
+                      f"s/tile={t_tile:.2f} s_register={t_reg:.1f} s_resample={t_res:.1f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per U-Net pass (sizes the activation workspace)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oai_analysis_2_amd import _lib
+    from oai_analysis_2_amd.image import Image
+    from oai_analysis_2_amd.pipeline import OVERLAP_ZYX, TILE_ZYX, VolumePipeline
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine, tile_grid
+    from oai_analysis_2_amd.synth import make_icon_state_dict, make_unet_state_dict, make_volume
+    _lib.load()                                                           # fail loudly if the HIP library is missing
+
+    unet_sd = make_unet_state_dict(0)
+    icon_sd = make_icon_state_dict(0, last_scale=0.1)
+    unet = UNetEngine(unet_sd)
+    icon = IconEngine(icon_sd)
+    atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
+    pipe = VolumePipeline(unet, icon, atlas, batch=args.batch)
+    n_distinct = 2
+    vols_np = [make_volume(100 * rank + i, VOL_SHAPE) for i in range(n_distinct)]
+    vols = [torch.from_numpy(v).cuda() for v in vols_np]                  # resident in HBM before timing
+    meta = Image(vols_np[0], [0.36, 0.36, 0.7], [2.0, -3.0, 1.0])
+
+    def step(i):
+        return pipe.run(vols[i % n_distinct], meta)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    unet.profile_read()
+    unet.profile(True)                                                    # HIP events around the dominant kernel
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_launches = unet.profile_read()
+    unet.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
+        alg_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles * args.steps    # this rank's volumes
+        achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32",
+            "value": world * args.steps / dt, "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
+                                   "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
+                       "tiles_per_pass": args.batch, "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": alg_conv3 / max(conv_launches, 1),
+                         "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
+            "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vols_np[0], meta, atlas, unet_sd, icon_sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

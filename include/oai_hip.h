@@ -139,8 +139,16 @@ int oai_stitch_blocks(const float* blocks_dev, int n_classes, int D, int H, int 
                       const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
                       float* maps_dev, void* stream);
 
+/* Roofline instrumentation (bench.py): when enabled, every launch of the dominant kernel (the 3x3x3
+ * implicit-GEMM conv) is bracketed by hipEvents on the launch stream.  oai_unet_profile_read waits for the
+ * recorded events and returns their summed duration and launch count, then clears them. */
+int oai_unet_profile(oai_unet* h, int enable);
+int oai_unet_profile_read(oai_unet* h, double* conv3_ms, long long* conv3_launches);
+
 /* Algorithmic FLOPs (2*MACs) of one tile, full or with the dead-output trim. */
 double oai_unet_tile_flops(const oai_unet* h, int td, int th, int tw, const int overlap_zyx[3], int trimmed);
+/* Same, restricted to the layers the 3x3x3 implicit-GEMM kernel runs (ec1-ec7, dc8, dc7, dc5, dc4, dc2, dc1). */
+double oai_unet_tile_flops_conv3(const oai_unet* h, int td, int th, int tw, const int overlap_zyx[3], int trimmed);
 
 /* ------------------------------------------------------------------------------------------
  * ICON registration network.  Replaces icon_registration.pretrained_models.

@@ -52,6 +52,9 @@ SIGNATURES = {
     "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "oai_stitch_blocks": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _I3, _P, _P]),
     "oai_unet_tile_flops": (_D, [_P, _I, _I, _I, _I3, _I]),
+    "oai_unet_tile_flops_conv3": (_D, [_P, _I, _I, _I, _I3, _I]),
+    "oai_unet_profile": (_I, [_P, _I]),
+    "oai_unet_profile_read": (_I, [_P, C.POINTER(_D), C.POINTER(C.c_longlong)]),
     "oai_icon_create": (_I, [C.POINTER(IconUnetParams), _I, _I, _I, C.POINTER(_P)]),
     "oai_icon_destroy": (None, [_P]),
     "oai_icon_workspace_bytes": (_Z, [_P]),

@@ -29,6 +29,9 @@ struct oai_unet {
     int variant = 0;                    // 0: MREP4/KC8, 1: MREP2/KC16
     int n_classes = 0;
     std::vector<void*> allocs;
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;      // reused start/stop pairs
+    size_t ev_used = 0;
 };
 
 namespace oai {
@@ -167,9 +170,24 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     a.ncb = (L.cout + 63) / 64;
     a.relu = 1;
     const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    oai_unet* hm = const_cast<oai_unet*>(h);
+    if (h->profile) {
+        if (hm->ev_used + 2 > hm->ev_pool.size()) {
+            hipEvent_t e0, e1;
+            OAI_CHECK_HIP(hipEventCreate(&e0));
+            OAI_CHECK_HIP(hipEventCreate(&e1));
+            hm->ev_pool.push_back(e0);
+            hm->ev_pool.push_back(e1);
+        }
+        OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
+    }
     if (h->variant == 1) conv3_igemm_f32<2, 16><<<grid, 256, 0, st>>>(a);
     else conv3_igemm_f32<4, 8><<<grid, 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
+    if (h->profile) {
+        OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
+        hm->ev_used += 2;
+    }
     return OAI_OK;
 }
 
@@ -322,8 +340,43 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
     return OAI_OK;
 }
 
+int oai_unet_profile(oai_unet* h, int enable) {
+    OAI_CHECK_ARG(h, "oai_unet_profile: null handle");
+    h->profile = enable != 0;
+    return OAI_OK;
+}
+
+int oai_unet_profile_read(oai_unet* h, double* conv3_ms, long long* conv3_launches) {
+    OAI_CHECK_ARG(h && conv3_ms && conv3_launches, "oai_unet_profile_read: null pointer");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        OAI_CHECK_HIP(hipEventSynchronize(h->ev_pool[i + 1]));
+        float t = 0.0f;
+        OAI_CHECK_HIP(hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
+        ms += t;
+    }
+    *conv3_ms = ms;
+    *conv3_launches = (long long)(h->ev_used / 2);
+    h->ev_used = 0;
+    return OAI_OK;
+}
+
+double oai_unet_tile_flops_conv3(const oai_unet* h, int td, int th, int tw, const int overlap[3], int trimmed) {
+    if (!h) return 0.0;
+    const int tile[3] = {td, th, tw};
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) { lo[i] = overlap ? overlap[i] : 0; hi[i] = tile[i] - lo[i]; }
+    Box need[18];
+    plan_regions(tile, lo, hi, trimmed != 0, need);
+    double f = 0;
+    for (int k = 1; k < 17; ++k)
+        if (kKind[k] == 0 || kKind[k] == 1) f += layer_flops(h, k, need[k]);
+    return f;
+}
+
 void oai_unet_destroy(oai_unet* h) {
     if (!h) return;
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }

@@ -1,0 +1,67 @@
+"""The per-volume hot path, device resident end to end:
+
+    DESS volume (fp32, [z,y,x]) --segment--> FC/TC probability maps --+
+                                --register--> phi (atlas -> patient) --+--> FC/TC on the atlas grid
+
+i.e. AnalysisObject.segment + AnalysisObject.register + the two ``deform_probmap`` calls of the
+reference's pipeline (test/test_all.py:54-58, dask_processing.py:46-125), without any host round trip.
+Used by bench.py, the cohort driver and the multi-GPU sharding.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .image import Image
+from .registration import IconEngine, resample_affines
+from .segmentation.engine import UNetEngine, tile_grid
+
+TILE_ZYX = (32, 128, 128)        # patch_size (128,128,32) in x,y,z (a2)
+OVERLAP_ZYX = (8, 16, 16)        # overlap_size (16,16,8) in x,y,z (analysis_object.py:23)
+CROP_ZYX = (8, 16, 16)           # assemble's frame: crop_size[2], [0], [1]
+
+
+@dataclass
+class VolumeResult:
+    fc: torch.Tensor             # [z,y,x] probability map, patient grid
+    tc: torch.Tensor
+    phi: torch.Tensor            # [3,D,H,W] dense map, network grid, [0,1] units
+    fc_atlas: torch.Tensor       # FC pulled onto the atlas grid through phi
+    tc_atlas: torch.Tensor
+
+
+class VolumePipeline:
+    def __init__(self, unet: UNetEngine, icon: IconEngine, atlas: Image, tile_zyx=TILE_ZYX, overlap_zyx=OVERLAP_ZYX,
+                 crop_zyx=CROP_ZYX, batch: int = 16):
+        self.unet, self.icon, self.atlas = unet, icon, atlas
+        self.tile_zyx, self.overlap_zyx, self.crop_zyx, self.batch = tuple(tile_zyx), tuple(overlap_zyx), tuple(crop_zyx), batch
+        self.atlas_dev = torch.from_numpy(np.ascontiguousarray(atlas.array, dtype=np.float32)).to(unet.device)
+        self._atlas_net = None
+
+    def segment(self, vol: torch.Tensor, out_mode: int = 0, tile_range: Optional[Tuple[int, int]] = None):
+        blocks = self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, tile_range, out_mode, self.batch)
+        if tile_range is not None:
+            return blocks
+        return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
+
+    def register(self, vol: torch.Tensor) -> torch.Tensor:
+        """phi_AB with A = patient volume (fixed), B = atlas (moving): registration.py:22-27."""
+        A = ops.resize_trilinear(vol[None], self.icon.net_shape)[0]
+        if self._atlas_net is None:      # the atlas is the same for every volume: resize it once
+            self._atlas_net = ops.resize_trilinear(self.atlas_dev[None], self.icon.net_shape)[0]
+        return self.icon.phi(A, self._atlas_net)
+
+    def resample(self, maps: torch.Tensor, phi: torch.Tensor, meta_A: Image):
+        disp = ops.phi_to_itk_displacement(phi)
+        b2n, n2a = resample_affines(meta_A, self.atlas, self.icon.net_shape)
+        return [ops.resample_through_disp(maps[c], disp, b2n, n2a, self.atlas.array.shape) for c in range(maps.shape[0])]
+
+    def run(self, vol: torch.Tensor, meta_A: Image) -> VolumeResult:
+        maps = self.segment(vol)
+        phi = self.register(vol)
+        fc_a, tc_a = self.resample(maps, phi, meta_A)
+        return VolumeResult(maps[0], maps[1], phi, fc_a, tc_a)

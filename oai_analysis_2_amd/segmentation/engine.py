@@ -100,6 +100,18 @@ class UNetEngine:
     def tile_flops(self, tile_zyx, overlap_zyx, trimmed: bool) -> float:
         return float(self.lib.oai_unet_tile_flops(self._h, *[int(v) for v in tile_zyx], _lib.int3(overlap_zyx), int(trimmed)))
 
+    def tile_flops_conv3(self, tile_zyx, overlap_zyx, trimmed: bool) -> float:
+        return float(self.lib.oai_unet_tile_flops_conv3(self._h, *[int(v) for v in tile_zyx], _lib.int3(overlap_zyx), int(trimmed)))
+
+    def profile(self, enable: bool) -> None:
+        _lib.check(self.lib.oai_unet_profile(self._h, int(enable)), "oai_unet_profile")
+
+    def profile_read(self):
+        """(summed ms, launches) of the 3x3x3 implicit-GEMM kernel since the last read (HIP events on its stream)."""
+        ms, n = C.c_double(), C.c_longlong()
+        _lib.check(self.lib.oai_unet_profile_read(self._h, C.byref(ms), C.byref(n)), "oai_unet_profile_read")
+        return ms.value, n.value
+
     def forward_tiles(self, tiles: torch.Tensor, batch: Optional[int] = None) -> torch.Tensor:
         """logits[B,n_classes,d,h,w] = model(tiles[B,1,d,h,w]) -- the ``self.model(...)`` of segmenter.py:116."""
         if tiles.dim() != 5 or tiles.shape[1] != 1:

@@ -1,0 +1,56 @@
+"""``Partition`` with the reference's interface (image_transforms.py:371-519), tiles as addressing.
+
+On the HIP path no tile tensor is ever materialised for ``segment`` (the first conv gathers straight
+from the resident volume with the same reflect-pad index math).  ``__call__`` and ``assemble`` are kept
+for callers that use them directly; they produce/consume device tensors.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..image import Image, as_image
+from .engine import tile_grid
+
+
+class Partition(object):
+    def __init__(self, tile_size, overlap_size, padding_mode="reflect", mode="eval"):
+        if padding_mode != "reflect":
+            raise NotImplementedError("only padding_mode='reflect' (the reference's pred configuration)")
+        self.tile_size = np.flipud(np.asarray(tile_size))          # (x,y,z) -> (z,y,x)   :389-391
+        self.overlap_size = np.flipud(np.asarray(overlap_size))
+        self.padding_mode, self.mode = padding_mode, mode
+
+    def geometry(self, image_size_zyx):
+        self.image_size = np.asarray(image_size_zyx)
+        eff, grid, n = tile_grid(image_size_zyx, self.tile_size, self.overlap_size)
+        self.effective_size, self.tiles_grid_size = np.asarray(eff), np.asarray(grid)
+        return eff, grid, n
+
+    def __call__(self, sample):
+        """{'image': Image|array} -> {'image': torch [N,1,d,h,w] on the current HIP device} (:395-455)."""
+        img = as_image(sample["image"])
+        self.image, self.name = img, sample.get("name", "")
+        vol = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32)).cuda()
+        eff, grid, n = self.geometry(vol.shape)
+        t, o = [int(v) for v in self.tile_size], [int(v) for v in self.overlap_size]
+
+        def refl(idx, size):           # numpy.pad(mode='reflect') index map
+            p = 2 * (size - 1)
+            m = torch.remainder(idx, p)
+            return torch.where(m < size, m, p - m)
+
+        dev = vol.device
+        tiles = torch.empty((n, 1, *t), dtype=torch.float32, device=dev)
+        k = 0
+        for i in range(grid[0]):
+            zi = refl(torch.arange(i * eff[0] - o[0], i * eff[0] - o[0] + t[0], device=dev), vol.shape[0])
+            for j in range(grid[1]):
+                yi = refl(torch.arange(j * eff[1] - o[1], j * eff[1] - o[1] + t[1], device=dev), vol.shape[1])
+                for kk in range(grid[2]):
+                    xi = refl(torch.arange(kk * eff[2] - o[2], kk * eff[2] - o[2] + t[2], device=dev), vol.shape[2])
+                    tiles[k, 0] = vol[zi][:, yi][:, :, xi]
+                    k += 1
+        sample = dict(sample)
+        sample["image"] = tiles
+        return sample

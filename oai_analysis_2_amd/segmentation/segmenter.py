@@ -1,0 +1,108 @@
+"""``Segmenter3DInPatchClassWise`` with the reference's constructor, config keys and ``segment`` signature
+(oai_analysis/segmentation/segmenter.py:90-131) on the MI355X path.
+
+What differs underneath: the volume is uploaded once; Partition / the tile-batch loop / sigmoid /
+threshold / assemble all run on the device through liboai_hip.so (oai_segment_tiles +
+oai_stitch_blocks); one D2H copy returns the two stitched maps.
+"""
+from __future__ import annotations
+
+import json
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from ..image import Image, as_image
+from .engine import tile_grid
+from .networks import get_network
+from .utils import initialize_model
+
+
+def load_json_to_dict(json_file):
+    """The training config is JSON (despite its .pth.tar name): segmenter.py:14-17, module_parameters.py:38-50."""
+    with open(json_file) as f:
+        return json.load(f)
+
+
+class Segmenter(ABC):
+    @abstractmethod
+    def __init__(self, *args, **kwargs):
+        self.model = None
+        self.config = None
+
+    @abstractmethod
+    def segment(self, *args, **kwargs):
+        pass
+
+
+class Segmenter3DInPatch(Segmenter):
+    def __init__(self, mode=None, config=None):
+        self.model = None
+        self.config = config
+        self.ready = False
+
+    def pred_setup(self):
+        """segmenter.py:51-62: read the JSON config, build the network, strict-load the checkpoint."""
+        training_config = load_json_to_dict(self.config["training_config_file"])
+        self.patch_size = tuple(int(v) for v in training_config["patch_size"])            # (x,y,z)
+        self.tile_zyx = self.patch_size[::-1]
+        net_cls = get_network(training_config["model"])
+        if net_cls is None:
+            raise NotImplementedError("model %r is not available on the MI355X path" % (training_config["model"],))
+        self.model = net_cls(**training_config["model_setting"])
+        device = self.config.get("device", "cuda")
+        if str(device).startswith("cpu"):
+            raise RuntimeError("device='cpu' requested: this package is the MI355X path and has no CPU fallback")
+        self.device = torch.device(device if str(device) != "cuda" else "cuda:%d" % torch.cuda.current_device())
+        initialize_model(self.model, ckpoint_path=self.config["ckpoint_path"])
+        self.model.to(self.device)
+        self.model.eval()
+        self.ready = True
+
+    def train(self, *args, **kwargs):      # the reference's training entry points are stubs (segmenter.py:64-70)
+        raise NotImplementedError("inference only")
+
+    def test(self, *args, **kwargs):
+        pass
+
+    def segment(self, image):
+        pass
+
+
+class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
+    def __init__(self, mode=None, config=None):
+        super().__init__(mode, config)
+
+    def segment_array(self, vol_zyx, if_output_prob_map=False, tile_range=None, as_device_tensor=False):
+        """numpy/torch [z,y,x] fp32 -> maps [n_classes, z, y, x] (fp32; the f64 cast happens at the API edge)."""
+        if not self.ready:
+            self.pred_setup()
+        eng = self.model.engine
+        vol = torch.as_tensor(np.ascontiguousarray(vol_zyx, dtype=np.float32) if not torch.is_tensor(vol_zyx) else vol_zyx)
+        vol = vol.to(eng.device, torch.float32)
+        ovl_xyz = tuple(int(v) for v in self.config["overlap_size"])
+        ovl_zyx = ovl_xyz[::-1]
+        crop_zyx = (ovl_xyz[2], ovl_xyz[0], ovl_xyz[1])        # assemble's crop_size indexing, image_transforms.py:511-512
+        # batch_size of the reference config is a host-loop knob (4 tiles per H2D/D2H round trip, segmenter.py:109-119);
+        # here it only sizes the activation workspace, so use a device-sized batch unless told otherwise
+        batch = int(self.config.get("device_batch_size", 16))
+        blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch)
+        if tile_range is not None:
+            return blocks
+        if min(crop_zyx) == 0:
+            # numpy's x[c:-c] with c == 0 is empty: the reference returns an all-zero map in that case
+            maps = torch.zeros((eng.n_classes, *vol.shape), dtype=torch.float32, device=eng.device)
+        else:
+            maps = eng.stitch(blocks, vol.shape, self.tile_zyx, ovl_zyx, crop_zyx)
+        return maps if as_device_tensor else maps.cpu().numpy()
+
+    def segment(self, image, if_output_prob_map=False, if_output_itk=True):
+        """(FC, TC) exactly like segmenter.py:100-131: float64 maps (prob) or bool-valued maps (mask)."""
+        img = as_image(image)
+        maps = self.segment_array(img.array, if_output_prob_map)
+        outs = []
+        for c in range(2):
+            arr = maps[c].astype(np.float64)           # Partition.assemble returns float64 (image_transforms.py:493)
+            outs.append(img.like(arr) if if_output_itk else arr)
+        return outs[0], outs[1]
