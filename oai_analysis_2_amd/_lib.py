@@ -70,6 +70,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; import it first so that liboai_hip.so binds to the SAME HIP
+    # runtime instance (two runtimes in one process do not share devices, streams or allocations).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise OaiError(f"{LIB_PATH} is missing: build it with `python -m oai_analysis_2_amd.build` "
                        "(there is no CPU fallback in this package)")
