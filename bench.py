@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="tiles per U-Net pass (sizes the activation workspace)")
+    ap.add_argument("--batch", type=int, default=32, help="tiles per U-Net pass (sizes the activation workspace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -45,7 +45,7 @@ icon_conv3_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
     for (int ci = 0; ci < Cin; ++ci) {
         const float* xp = x + ci * plane;
         const float* wp = wk + ((long long)ci * 27) * Cout + cg * COUT_T;
-#pragma unroll
+#pragma unroll 3
         for (int t = 0; t < 27; ++t) {
             const int iz = iz0 + t / 9, iy = iy0 + (t / 3) % 3, ix = ix0 + t % 3;
             float in = 0.0f;
@@ -111,7 +111,7 @@ icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
     for (int ci = 0; ci < Cin; ++ci) {
         const float* xp = x + ci * plane;
         const float* wp = wk + ((long long)ci * 64) * Cout + cg * COUT_T;
-#pragma unroll
+#pragma unroll 2
         for (int t = 0; t < 8; ++t) {
             const int kz = qz + 2 * (t >> 2), ky = qy + 2 * ((t >> 1) & 1), kx = qx + 2 * (t & 1);
             const int iz = (oz + 1 - kz) >> 1, iy = (oy + 1 - ky) >> 1, ix = (ox + 1 - kx) >> 1;

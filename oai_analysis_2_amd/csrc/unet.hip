@@ -156,19 +156,13 @@ static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch)
     return p;
 }
 
-static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
-                        const int dims[3], const Box& box, int ntiles, hipStream_t st) {
-    ConvArgs a;
-    a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
-    a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
-    a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
+template <int MREP, int KC, int RX, int RY, int WY, int WX>
+static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
-    const int TZ = h->variant == 1 ? 2 : 4;
-    a.nbz = cdiv(box.hi[0] - box.lo[0], TZ);
-    a.nby = cdiv(box.hi[1] - box.lo[1], kConvTY);
-    a.nbx = cdiv(box.hi[2] - box.lo[2], kConvTX);
-    a.ncb = (L.cout + 63) / 64;
-    a.relu = 1;
+    if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
+    a.nbz = cdiv(box.hi[0] - box.lo[0], MREP);
+    a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
+    a.nbx = cdiv(box.hi[2] - box.lo[2], WX * RX);
     const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
     oai_unet* hm = const_cast<oai_unet*>(h);
     if (h->profile) {
@@ -181,12 +175,50 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-    if (h->variant == 1) conv3_igemm_f32<2, 16><<<grid, 256, 0, st>>>(a);
-    else conv3_igemm_f32<4, 8><<<grid, 256, 0, st>>>(a);
+    conv3_igemm_f32<MREP, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
     if (h->profile) {
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
         hm->ev_used += 2;
+    }
+    return OAI_OK;
+}
+
+// One conv layer = the main launch over the part of the output box that 8 x 16 (y, x) tiles cover exactly, plus up
+// to two thin remainder strips computed with tile shapes that fit them (trimmed boxes are e.g. 18 x 98 x 98).
+static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
+                        const int dims[3], const Box& box, int ntiles, hipStream_t st) {
+    ConvArgs a;
+    a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
+    a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
+    a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
+    a.ncb = (L.cout + 63) / 64;
+    a.relu = 1;
+    if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
+    const int ry = box.hi[1] - box.lo[1], rx = box.hi[2] - box.lo[2];
+    int ny = ry / 8, nx = rx / 16;
+    int hr = ry - 8 * ny, wr = rx - 16 * nx;
+    if (h->variant == 2 || ny == 0 || nx == 0) { ny = cdiv(ry, 8); nx = cdiv(rx, 16); hr = wr = 0; }   // no strips
+    if (hr > 4) { ++ny; hr = 0; }            // a tall remainder is cheaper as one more row of main tiles
+    if (wr > 8) { ++nx; wr = 0; }
+    Box main = box, xs = box, ys = box;
+    main.hi[1] = hr ? box.lo[1] + 8 * ny : box.hi[1];
+    main.hi[2] = wr ? box.lo[2] + 16 * nx : box.hi[2];
+    int rc = launch_conv3_shape<4, 8, 16, 2, 4, 1>(h, a, main, ntiles, st);
+    if (rc) return rc;
+    if (wr) {                                 // x strip: all y rows, the last wr columns
+        xs.lo[2] = main.hi[2];
+        if (wr <= 2) rc = launch_conv3_shape<4, 8, 2, 16, 4, 1>(h, a, xs, ntiles, st);
+        else if (wr <= 4) rc = launch_conv3_shape<4, 8, 4, 8, 4, 1>(h, a, xs, ntiles, st);
+        else rc = launch_conv3_shape<4, 8, 8, 4, 4, 1>(h, a, xs, ntiles, st);
+        if (rc) return rc;
+    }
+    if (hr) {                                 // y strip: the last hr rows, main columns only
+        ys.lo[1] = main.hi[1];
+        ys.hi[2] = main.hi[2];
+        if (hr <= 2) rc = launch_conv3_shape<4, 8, 16, 2, 1, 4>(h, a, ys, ntiles, st);
+        else rc = launch_conv3_shape<4, 8, 16, 2, 2, 2>(h, a, ys, ntiles, st);
+        if (rc) return rc;
     }
     return OAI_OK;
 }
@@ -226,8 +258,12 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     const size_t v0 = (size_t)src.td * src.th * src.tw;
 
     {   // ec0 (+ gather)
-        dim3 grid(cdiv(v0, 256), L[EC0].cout / 8, n);
-        conv3_first_kernel<<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], L[EC0].cout, 1);
+        dim3 grid(cdiv(v0 / 2, 256), n);
+        const int c = L[EC0].cout;
+        if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
+        else if (c == 16) conv3_first_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
+        else if (c == 8) conv3_first_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
+        else return set_error(OAI_ERR_ARG, "ec0 cout %d unsupported (8, 16 or 32)", c);
         OAI_CHECK_LAUNCH();
     }
     int rc;

@@ -42,16 +42,23 @@ struct ConvArgs {
     int relu;
 };
 
-constexpr int kConvTY = 8, kConvTX = 16, kConvHY = kConvTY + 2, kConvHX = kConvTX + 2;
 
-template <int MREP, int KC>
+// Tile shape: a 32-row MFMA block is RX x RY voxels (x, y); the 4 waves are arranged WY x WX, so a workgroup covers
+// MREP x (WY*RY) x (WX*RX) voxels.  The main shape is <16,2,4,1> (4 x 8 x 16); the other shapes exist for the thin
+// remainder strips of trimmed output boxes (e.g. 98 = 6*16 + 2), see launch_conv3 in unet.hip.  Every shape
+// accumulates each output voxel in the same k order, so the result does not depend on the shape used.
+template <int MREP, int KC, int RX, int RY, int WY, int WX>
 __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
+    static_assert(RX * RY == 32 && WY * WX == 4, "bad tile shape");
+    constexpr int kConvTY = WY * RY, kConvTX = WX * RX, kConvHY = kConvTY + 2, kConvHX = kConvTX + 2;
     constexpr int NREP = 2;
     constexpr int TZ = MREP, HZ = TZ + 2;
     constexpr int STRIDE = KC + 4;                 // floats per halo voxel (16-byte pad: bank spread)
     constexpr int HVOX = HZ * kConvHY * kConvHX;
     constexpr int Q = KC / 4;                      // float4 per voxel per chunk
     constexpr int KG = KC / 8;                     // k-groups (8 channels = 4 MFMA steps) per chunk
+    constexpr int NSLOT = (HVOX * Q + 255) / 256;  // halo float4 slots per thread
+    constexpr int NSTEP = 27 * KG;                 // (tap, k-group) steps per chunk
     __shared__ __attribute__((aligned(16))) float lds[HVOX * STRIDE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,6 +69,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
     const int bz = id % a.nbz; id /= a.nbz;
     const int tile = id;
     const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * kConvTY, ox0 = a.lo[2] + bx * kConvTX;
+    const int mvalid = min(MREP, a.hi[0] - oz0);   // z slices of this block inside the output box (uniform)
 
     f32x16 acc[MREP][NREP];
 #pragma unroll
@@ -72,70 +80,91 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
     const int row = lane & 31, half = lane >> 5;
-    const int lx = row & 15, ly = 2 * wave + (row >> 4);
-    // LDS float offset of this lane's voxel for row block m, tap (0,0,0)
-    const int a_base = (ly * kConvHX + lx) * STRIDE + 4 * half;
+    const int wy = wave / WX, wx = wave % WX;
+    const int lx = wx * RX + row % RX, ly = wy * RY + row / RX;
+    // LDS float offset of this lane's voxel for row block 0, tap (0,0,0)
+    const float* a_ptr = &lds[(ly * kConvHX + lx) * STRIDE + 4 * half];
 
     const int nch0 = (a.C0 + KC - 1) / KC, nch1 = (a.C1 + KC - 1) / KC;
     const int nchunks = nch0 + nch1;
-    const float4* wp = a.wpanel + (size_t)cb * nchunks * 27 * KG * NREP * 64 + lane;
+    const float4* wp = a.wpanel + (size_t)cb * nchunks * NSTEP * NREP * 64 + lane;
     const size_t plane = (size_t)a.D * a.H * a.W;
 
-    float4 bnext[NREP];
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
-    wp += NREP * 64;
-
-    for (int ch = 0; ch < nchunks; ++ch) {
+    // ---- halo staging, split in two: issue the global loads early, write LDS late (T14) ----------------
+    float4 hreg[NSLOT];
+    auto halo_load = [&](int ch) {
         const bool first = ch < nch0;
         const float* src = first ? a.src0 : a.src1;
         const int C = first ? a.C0 : a.C1;
         const int c0 = (first ? ch : ch - nch0) * KC;
         const float* sbase = src + (size_t)tile * plane * C + c0;
-        __syncthreads();                                     // all waves done with the previous chunk
-        for (int slot = tid; slot < HVOX * Q; slot += 256) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int slot = tid + i * 256;
             const int hv = slot / Q, q = slot - hv * Q;
             const int hx = hv % kConvHX;
             const int t2 = hv / kConvHX;
             const int hy = t2 % kConvHY, hz = t2 / kConvHY;
             const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
-                c0 + 4 * q < C)
+            if (slot < HVOX * Q && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H &&
+                (unsigned)gx < (unsigned)a.W && c0 + 4 * q < C)
                 v = *reinterpret_cast<const float4*>(sbase + (((size_t)gz * a.H + gy) * a.W + gx) * C + 4 * q);
-            *reinterpret_cast<float4*>(&lds[hv * STRIDE + 4 * q]) = v;
+            hreg[i] = v;
         }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int slot = tid + i * 256;
+            const int hv = slot / Q, q = slot - hv * Q;
+            if (slot < HVOX * Q) *reinterpret_cast<float4*>(&lds[hv * STRIDE + 4 * q]) = hreg[i];
+        }
+    };
+
+    float4 bcur[NREP], bnext[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) bcur[n] = wp[n * 64];
+    wp += NREP * 64;
+    halo_load(0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                                     // every wave is done reading the previous chunk
+        halo_store();
         __syncthreads();
-#pragma unroll 1
-        for (int dz = 0; dz < 3; ++dz) {
+        if (ch + 1 < nchunks) halo_load(ch + 1);             // in flight behind this chunk's 27*KG*MREP*8 MFMAs
 #pragma unroll
-            for (int dyx = 0; dyx < 9; ++dyx) {
-                const int dy = dyx / 3, dx = dyx % 3;
+        for (int st = 0; st < NSTEP; ++st) {
+            const int t = st / KG, kg = st % KG;
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            // this step's A fragments (LDS, ~100 cycles) and the NEXT step's B fragments (L2, ~600 cycles),
+            // pinned above this step's MFMAs so that the weight loads have a whole step to land
+            float4 acur[MREP];
 #pragma unroll
-                for (int kg = 0; kg < KG; ++kg) {
-                    float4 bcur[NREP];
+            for (int m = 0; m < MREP; ++m)
+                acur[m] = *reinterpret_cast<const float4*>(
+                    a_ptr + (((m + dz) * kConvHY + dy) * kConvHX + dx) * STRIDE + 8 * kg);
 #pragma unroll
-                    for (int n = 0; n < NREP; ++n) { bcur[n] = bnext[n]; bnext[n] = wp[n * 64]; }
-                    wp += NREP * 64;
-                    float4 af[MREP];
+            for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
+            wp += NREP * 64;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < MREP; ++m)
-                        af[m] = *reinterpret_cast<const float4*>(
-                            &lds[a_base + (((m + dz) * kConvHY + dy) * kConvHX + dx) * STRIDE + 8 * kg]);
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
+                for (int m = 0; m < MREP; ++m) {
+                    if (m < mvalid) {
+                        const float av = s == 0 ? acur[m].x : s == 1 ? acur[m].y : s == 2 ? acur[m].z : acur[m].w;
 #pragma unroll
-                        for (int m = 0; m < MREP; ++m) {
-                            const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
-#pragma unroll
-                            for (int n = 0; n < NREP; ++n) {
-                                const float bv = s == 0 ? bcur[n].x : s == 1 ? bcur[n].y : s == 2 ? bcur[n].z : bcur[n].w;
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
-                            }
+                        for (int n = 0; n < NREP; ++n) {
+                            const float bv = s == 0 ? bcur[n].x : s == 1 ? bcur[n].y : s == 2 ? bcur[n].z : bcur[n].w;
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
                         }
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bcur[n] = bnext[n];
         }
     }
 
@@ -152,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int ox = ox0 + (rr & 15), oy = oy0 + 2 * wave + (rr >> 4);
+                const int ox = ox0 + wx * RX + rr % RX, oy = oy0 + wy * RY + rr / RX;
                 if (ox < a.hi[2] && oy < a.hi[1]) {
                     float v = acc[m][n][r] * sc + sh;
                     if (a.relu) v = fmaxf(v, 0.0f);
@@ -218,14 +247,22 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
 
     const int nkg = (a.Cin + 7) / 8;
     const float4* wp = a.wpanel + (size_t)(ncol0 / 64) * nkg * 2 * 64 + lane;
-    for (int kg = 0; kg < nkg; ++kg) {
-        float4 af[2], bf[2];
+    auto load_a = [&](int kg, float4 (&af)[2]) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
             af[m] = (av[m] && kg * 8 + 4 * half < a.Cin) ? *reinterpret_cast<const float4*>(ap[m] + kg * 8)
                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 af[2], bf[2], afn[2], bfn[2];
+    load_a(0, af);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bf[n] = wp[(kg * 2 + n) * 64];
+    for (int n = 0; n < 2; ++n) bf[n] = wp[n * 64];
+    for (int kg = 0; kg < nkg; ++kg) {
+        // next k-group's fragments in flight behind this k-group's 16 MFMAs (panel has one k-group of slack)
+        load_a(kg + 1 < nkg ? kg + 1 : kg, afn);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bfn[n] = wp[((kg + 1 < nkg ? kg + 1 : kg) * 2 + n) * 64];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -237,9 +274,26 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[m][n], 0, 0, 0);
                 }
             }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[m] = afn[m];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = bfn[n];
     }
-    const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
-    (void)Do;
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    // rows of this lane: v = mb*64 + m*32 + 8*g + 4*half + j  (g = r>>2, j = r&3).  Decompose the 8 group bases
+    // once (two integer divisions each) and walk j with carries instead of dividing per element.
+    int vx[2][4], vy[2][4], vz[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int v = mb * 64 + m * 32 + 8 * g + 4 * half;
+            vx[m][g] = v % rx;
+            const int t = v / rx;
+            vy[m][g] = t % ry;
+            vz[m][g] = t / ry;
+        }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = ncol0 + n * 32 + row;
@@ -247,18 +301,21 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
         const int par = col / a.Cout, co = col - par * a.Cout;
         const int pa = par >> 2, pb = (par >> 1) & 1, pc = par & 1;
         const float sc = a.scale[co], sh = a.shift[co];
+        float* obase = a.out + (size_t)tile * 8 * plane * a.Cout + co;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int v = mb * 64 + m * 32 + rr;
-                if (v < nvox) {
-                    const int x = v % rx, y = (v / rx) % ry, z = v / (rx * ry);
-                    const int oz = 2 * (a.lo[0] + z) + pa, oy = 2 * (a.lo[1] + y) + pb, ox = 2 * (a.lo[2] + x) + pc;
-                    float val = acc[m][n][r] * sc + sh;
-                    if (a.relu) val = fmaxf(val, 0.0f);
-                    a.out[((size_t)tile * 8 * plane + ((size_t)oz * Ho + oy) * Wo + ox) * a.Cout + co] = val;
+            for (int g = 0; g < 4; ++g) {
+                int x = vx[m][g], y = vy[m][g], z = vz[m][g];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (z < rz) {
+                        const int oz = 2 * (a.lo[0] + z) + pa, oy = 2 * (a.lo[1] + y) + pb, ox = 2 * (a.lo[2] + x) + pc;
+                        float val = acc[m][n][4 * g + j] * sc + sh;
+                        if (a.relu) val = fmaxf(val, 0.0f);
+                        obase[(((size_t)oz * Ho + oy) * Wo + ox) * a.Cout] = val;
+                    }
+                    if (++x == rx) { x = 0; if (++y == ry) { y = 0; ++z; } }
                 }
             }
     }
@@ -288,43 +345,91 @@ __device__ __forceinline__ int reflect_index(int v, int n) {
     return m < n ? m : p - m;
 }
 
-__device__ __forceinline__ float tile_voxel(const TileSource& s, int local_tile, int z, int y, int x) {
-    if ((unsigned)z >= (unsigned)s.td || (unsigned)y >= (unsigned)s.th || (unsigned)x >= (unsigned)s.tw) return 0.0f;
-    if (!s.vol) return s.tiles[(((size_t)local_tile * s.td + z) * s.th + y) * s.tw + x];
-    const int t = s.tile_begin + local_tile;
-    const int tk = t % s.gx, tj = (t / s.gx) % s.gy, ti = t / (s.gx * s.gy);
-    const int vz = reflect_index(ti * s.ez + z - s.oz, s.D);
-    const int vy = reflect_index(tj * s.ey + y - s.oy, s.H);
-    const int vx = reflect_index(tk * s.ex + x - s.ox, s.W);
-    return s.vol[((size_t)vz * s.H + vy) * s.W + vx];
-}
-
-__global__ void __launch_bounds__(256) conv3_first_kernel(const TileSource s, const float* __restrict__ wk /*[27][Cout]*/,
+// One thread = two x-adjacent voxels x all 32 (COUT) couts, so every voxel's 128-byte channel row is written
+// whole.  The per-axis neighbour indices (reflect-padded volume index, or -1 for a neighbour outside the TILE =
+// Conv3d's zero padding) are computed once; weights [27][COUT] sit in LDS and are read as broadcasts.
+template <int COUT>
+__global__ void __launch_bounds__(256) conv3_first_kernel(const TileSource s, const float* __restrict__ wk /*[27][COUT]*/,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ out, int Cout, int relu) {
+                                                          float* __restrict__ out, int relu) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) wl[i] = wk[i];
+    __syncthreads();
     const size_t plane = (size_t)s.td * s.th * s.tw;
-    const int local_tile = blockIdx.z;
-    const int cg = blockIdx.y;                       // group of 8 couts
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= plane) return;
-    const int x = (int)(v % s.tw), y = (int)((v / s.tw) % s.th), z = (int)(v / ((size_t)s.tw * s.th));
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int local_tile = blockIdx.y;
+    const int hw = s.tw >> 1;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;      // voxel-pair index
+    if (p >= plane / 2) return;
+    const int x = 2 * (int)(p % hw), y = (int)((p / hw) % s.th), z = (int)(p / ((size_t)hw * s.th));
+    int iz[3], iy[3], ix[4];
+    const float* base;
+    if (s.vol) {
+        const int t = s.tile_begin + local_tile;
+        const int tk = t % s.gx, tj = (t / s.gx) % s.gy, ti = t / (s.gx * s.gy);
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
-        const float in = tile_voxel(s, local_tile, z + dz, y + dy, x + dx);
+        for (int d = 0; d < 3; ++d) {
+            const int zz = z + d - 1, yy = y + d - 1;
+            iz[d] = (unsigned)zz < (unsigned)s.td ? reflect_index(ti * s.ez + zz - s.oz, s.D) * s.H * s.W : -1;
+            iy[d] = (unsigned)yy < (unsigned)s.th ? reflect_index(tj * s.ey + yy - s.oy, s.H) * s.W : -1;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(in, wk[t * Cout + cg * 8 + j], acc[j]);
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + d - 1;
+            ix[d] = (unsigned)xx < (unsigned)s.tw ? reflect_index(tk * s.ex + xx - s.ox, s.W) : -1;
+        }
+        base = s.vol;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int zz = z + d - 1, yy = y + d - 1;
+            iz[d] = (unsigned)zz < (unsigned)s.td ? zz * s.th * s.tw : -1;
+            iy[d] = (unsigned)yy < (unsigned)s.th ? yy * s.tw : -1;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + d - 1;
+            ix[d] = (unsigned)xx < (unsigned)s.tw ? xx : -1;
+        }
+        base = s.tiles + (size_t)local_tile * plane;
     }
-    float r[8];
+    float acc[2][COUT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r[j] = acc[j] * scale[cg * 8 + j] + shift[cg * 8 + j];
-        if (relu) r[j] = fmaxf(r[j], 0.0f);
+    for (int j = 0; j < COUT; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
+#pragma unroll 1
+    for (int zy = 0; zy < 9; ++zy) {
+        const int dz = zy / 3, dy = zy - 3 * dz;
+        const int a = dz == 0 ? iz[0] : dz == 1 ? iz[1] : iz[2];
+        const int b = dy == 0 ? iy[0] : dy == 1 ? iy[1] : iy[2];
+        float in[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) in[d] = (a | b | ix[d]) >= 0 ? base[(size_t)a + b + ix[d]] : 0.0f;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float* w = &wl[(zy * 3 + dx) * COUT];
+#pragma unroll
+            for (int j = 0; j < COUT; j += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(w + j);
+                acc[0][j] = fmaf(in[dx], w4.x, acc[0][j]);         acc[1][j] = fmaf(in[dx + 1], w4.x, acc[1][j]);
+                acc[0][j + 1] = fmaf(in[dx], w4.y, acc[0][j + 1]); acc[1][j + 1] = fmaf(in[dx + 1], w4.y, acc[1][j + 1]);
+                acc[0][j + 2] = fmaf(in[dx], w4.z, acc[0][j + 2]); acc[1][j + 2] = fmaf(in[dx + 1], w4.z, acc[1][j + 2]);
+                acc[0][j + 3] = fmaf(in[dx], w4.w, acc[0][j + 3]); acc[1][j + 3] = fmaf(in[dx + 1], w4.w, acc[1][j + 3]);
+            }
+        }
     }
-    float* o = out + ((size_t)local_tile * plane + v) * Cout + cg * 8;
-    *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+    const size_t v = ((size_t)z * s.th + y) * s.tw + x;
+    float* o = out + ((size_t)local_tile * plane + v) * COUT;
+#pragma unroll
+    for (int vv = 0; vv < 2; ++vv)
+#pragma unroll
+        for (int j = 0; j < COUT; j += 4) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[k] = acc[vv][j + k] * scale[j + k] + shift[j + k];
+                if (relu) r[k] = fmaxf(r[k], 0.0f);
+            }
+            *reinterpret_cast<float4*>(o + vv * COUT + j) = make_float4(r[0], r[1], r[2], r[3]);
+        }
 }
 
 // MaxPool3d(2) on channels-last: one thread = one output voxel x 4 channels

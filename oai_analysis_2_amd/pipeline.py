@@ -36,7 +36,7 @@ class VolumeResult:
 
 class VolumePipeline:
     def __init__(self, unet: UNetEngine, icon: IconEngine, atlas: Image, tile_zyx=TILE_ZYX, overlap_zyx=OVERLAP_ZYX,
-                 crop_zyx=CROP_ZYX, batch: int = 16):
+                 crop_zyx=CROP_ZYX, batch: int = 32):
         self.unet, self.icon, self.atlas = unet, icon, atlas
         self.tile_zyx, self.overlap_zyx, self.crop_zyx, self.batch = tuple(tile_zyx), tuple(overlap_zyx), tuple(crop_zyx), batch
         self.atlas_dev = torch.from_numpy(np.ascontiguousarray(atlas.array, dtype=np.float32)).to(unet.device)

@@ -127,7 +127,7 @@ class UNetEngine:
         return out
 
     def segment_tiles(self, vol: torch.Tensor, tile_zyx, overlap_zyx, tile_range: Optional[Tuple[int, int]] = None,
-                      out_mode: int = 0, batch: int = 16) -> torch.Tensor:
+                      out_mode: int = 0, batch: int = 32) -> torch.Tensor:
         """Kept-centre blocks [n_local, n_classes, ez, ey, ex] of tiles [begin,end) of the volume."""
         vol = vol.to(self.device, torch.float32).contiguous()
         D, H, W = vol.shape

@@ -17,4 +17,4 @@ for rep in range(2):
     fl_t = eng.tile_flops(tile, ovl, True) * ntiles; fl_f = eng.tile_flops(tile, ovl, False) * ntiles
     notrim = bool(int(os.environ.get("OAI_NO_TRIM", "0")))
     print(f"variant={os.environ.get('OAI_CONV_VARIANT','0')} notrim={notrim} tiles={ntiles} batch={batch} time={dt:.3f}s "
-          f"algorithmic {fl_t/dt/1e12:.1f} TF/s, executed-untrimmed-equivalent {fl_f/dt/1e12:.1f} TF/s, vol/s={160/ntiles/dt:.3f}")
+          f"algorithmic {fl_t/dt/1e12:.1f} TF/s, executed-untrimmed-equivalent {fl_f/dt/1e12:.1f} TF/s, vol/s={ntiles/160/dt:.3f}")
