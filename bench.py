@@ -126,6 +126,12 @@ def main():
         _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
         alg_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles * args.steps    # this rank's volumes
         achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic = None            # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32",
             "value": world * args.steps / dt, "unit": "volumes/s",
@@ -136,7 +142,7 @@ def main():
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": args.batch, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "algorithmic_flops_per_launch": alg_conv3 / max(conv_launches, 1),
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,

@@ -1,0 +1,82 @@
+"""GPU: the reference-surface classes (Segmenter3DInPatchClassWise, AnalysisObject, ICON_Registration,
+deform_probmap) driven exactly like the reference's own tests drive them (test/test_all.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oai_analysis_2_amd.image import Image
+from oai_analysis_2_amd.synth import make_icon_state_dict, make_unet_state_dict, make_volume
+from oracle import icon as oicon, resample as oresample, seg as oseg
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_models(td, patch, unet_seed, bn=False):
+    with open(os.path.join(td, "segmentation_train_config.pth.tar"), "w") as f:     # JSON under a .pth.tar name
+        json.dump({"patch_size": list(patch), "model": "UNet",
+                   "model_setting": {"in_channels": 1, "n_classes": 2, "bias": True, "BN": bn}}, f)
+    torch.save({"model_state_dict": make_unet_state_dict(seed=unet_seed, bn=bn), "epoch": 3, "best_score": 0.5},
+               os.path.join(td, "segmentation_model.pth.tar"))
+
+
+def test_segmenter_matches_reference_golden(golden_dir, tmp_path):
+    from oai_analysis_2_amd.segmentation.segmenter import Segmenter3DInPatchClassWise
+    z = np.load(os.path.join(golden_dir, "segment_small.npz"))
+    _write_models(str(tmp_path), tuple(int(v) for v in z["patch"]), int(z["weight_seed"]))
+    seg = Segmenter3DInPatchClassWise(mode="pred", config=dict(
+        ckpoint_path=str(tmp_path / "segmentation_model.pth.tar"),
+        training_config_file=str(tmp_path / "segmentation_train_config.pth.tar"),
+        device="cuda", batch_size=4, overlap_size=tuple(int(v) for v in z["overlap"]), output_prob=True, output_itk=True))
+    img = Image(make_volume(int(z["volume_seed"]), (24, 72, 72)), [0.36, 0.36, 0.7], [1, 2, 3])
+    fc, tc = seg.segment(img, if_output_prob_map=True, if_output_itk=True)
+    assert isinstance(fc, Image) and fc.array.dtype == np.float64 and np.allclose(fc.spacing, img.spacing)   # CopyInformation
+    budget = 12.0 * img.array.size / 23592960
+    assert np.abs(fc.array - z["fc_prob"]).sum() < budget and np.abs(tc.array - z["tc_prob"]).sum() < budget
+    fm, tm = seg.segment(img, if_output_prob_map=False, if_output_itk=False)
+    assert isinstance(fm, np.ndarray) and set(np.unique(fm)) <= {0.0, 1.0}
+    assert (fm.astype(np.uint8) != z["fc_mask"]).sum() <= 3 and (tm.astype(np.uint8) != z["tc_mask"]).sum() <= 3
+
+
+def test_segmenter_errors_like_the_reference(tmp_path):
+    from oai_analysis_2_amd.segmentation.networks import get_network
+    from oai_analysis_2_amd.segmentation.segmenter import Segmenter3DInPatchClassWise
+    _write_models(str(tmp_path), (32, 32, 16), 1)
+    cfg = dict(ckpoint_path=str(tmp_path / "missing.pth.tar"), training_config_file=str(tmp_path / "segmentation_train_config.pth.tar"),
+               device="cuda", batch_size=4, overlap_size=(8, 8, 4), output_prob=True, output_itk=True)
+    with pytest.raises(ValueError, match="no checkpoint found"):             # utils.py:41
+        Segmenter3DInPatchClassWise(mode="pred", config=cfg).segment(Image(make_volume(0, (16, 32, 32))))
+    cfg["ckpoint_path"] = str(tmp_path / "segmentation_model.pth.tar")
+    cfg["device"] = "cpu"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Segmenter3DInPatchClassWise(mode="pred", config=cfg).segment(Image(make_volume(0, (16, 32, 32))))
+    assert get_network("nope") is None                                       # networks.py:858-862
+
+
+def test_analysis_object_end_to_end(tmp_path):
+    """test_all.py:35-58: register, then deform both probability maps onto the atlas."""
+    from oai_analysis_2_amd.analysis_object import AnalysisObject
+    from oai_analysis_2_amd.registration import DisplacementTransform, deform_probmap
+    td = str(tmp_path)
+    _write_models(td, (64, 64, 32), 4)
+    icon_sd = make_icon_state_dict(3, last_scale=0.1)
+    torch.save(icon_sd, os.path.join(td, "icon_weights.pth"))
+    atlas = Image(make_volume(31, (40, 80, 88)), [0.4, 0.35, 0.75], [0.0, -1.0, 2.0])
+    np.savez(os.path.join(td, "atlas_image.npz"), array=atlas.array, spacing=atlas.spacing, origin=atlas.origin, direction=atlas.direction)
+    obj = AnalysisObject(models_dir=td)
+    obj.registerer.register_module = type(obj.registerer.register_module)(icon_sd, net_shape=(40, 48, 48))   # small net grid
+    img = Image(make_volume(30, (24, 72, 72)), [0.36, 0.37, 0.7], [1.0, 2.0, 3.0])
+    FC, TC = obj.segment_volume(img)                                          # alias of .segment
+    fc_ref, tc_ref = oseg.segment(img.array, make_unet_state_dict(4), (64, 64, 32), (16, 16, 8))
+    assert np.abs(FC.array - fc_ref).max() < 1e-5 and np.abs(TC.array - tc_ref).max() < 1e-5
+    phi = obj.register_to_atlas(img)                                          # alias of .register
+    assert isinstance(phi, DisplacementTransform) and phi.displacement.shape == (40, 48, 48, 3)
+    phi_ref, _ = oicon.register_pair_arrays(img.array, atlas.array, icon_sd, net_shape=(40, 48, 48), both=False)
+    disp_ref = oicon.displacement_itk(phi_ref)
+    assert np.abs(phi.displacement - disp_ref).max() < 1e-4 * max(1.0, np.abs(disp_ref).max())
+    warped = deform_probmap(phi, img, obj.atlas_image, FC)
+    ref = oresample.resample_through_phi(FC.array, disp_ref, img, atlas)
+    assert warped.array.shape == atlas.array.shape and warped.array.dtype == np.float64
+    assert np.abs(warped.array - ref).max() < 1e-4

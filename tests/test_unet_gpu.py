@@ -85,3 +85,22 @@ def test_segment_small_matches_reference_golden(golden_dir):
     # tile-range sharding (the multi-GPU path) produces the same blocks
     part = torch.cat([eng.segment_tiles(v, tile_zyx, ovl_zyx, (0, 30), 0, 8), eng.segment_tiles(v, tile_zyx, ovl_zyx, (30, 75), 0, 8)])
     assert torch.equal(part, blocks)
+
+
+def test_cohort_runner_matches_single_runs():
+    from oai_analysis_2_amd.cohort import CohortRunner
+    from oai_analysis_2_amd.image import Image
+    from oai_analysis_2_amd.pipeline import VolumePipeline
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    from oai_analysis_2_amd.synth import make_icon_state_dict
+    shape, net = (24, 72, 72), (40, 48, 48)
+    pipe = VolumePipeline(UNetEngine(make_unet_state_dict(1, width_div=2)), IconEngine(make_icon_state_dict(1, 0.1), net_shape=net),
+                          Image(make_volume(10, shape), [0.4, 0.4, 0.8]), tile_zyx=(16, 32, 32), overlap_zyx=(4, 8, 8), crop_zyx=(4, 8, 8), batch=8)
+    imgs = [Image(make_volume(20 + i, shape), [0.4, 0.4, 0.8], [i, 0, 0]) for i in range(3)]
+    got = dict(CohortRunner(pipe).run(imgs))
+    assert sorted(got) == [0, 1, 2]
+    for i, img in enumerate(imgs):
+        ref = pipe.run(torch.from_numpy(img.array).cuda(), img)
+        assert torch.equal(got[i].fc, ref.fc.cpu()) and torch.equal(got[i].tc_atlas, ref.tc_atlas.cpu()) and torch.equal(got[i].phi, ref.phi.cpu())
+    assert sorted(i for i, _ in CohortRunner(pipe).run(imgs, rank=1, world=2)) == [1]
