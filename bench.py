@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 VOL_SHAPE = (160, 384, 384)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
+PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3}
 
 
 def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
@@ -62,6 +64,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="tiles per U-Net pass (sizes the activation workspace)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"],
+                    help="arithmetic of the 3x3x3 conv layers: exact fp32 MFMA, or split-bf16 with 6 / 3 MFMA passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,7 +91,7 @@ def main():
 
     unet_sd = make_unet_state_dict(0)
     icon_sd = make_icon_state_dict(0, last_scale=0.1)
-    unet = UNetEngine(unet_sd)
+    unet = UNetEngine(unet_sd, precision=args.precision)
     icon = IconEngine(icon_sd)
     atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
     pipe = VolumePipeline(unet, icon, atlas, batch=args.batch)
@@ -126,6 +130,7 @@ def main():
         _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
         alg_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles * args.steps    # this rank's volumes
         achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
         traffic = None            # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -137,12 +142,16 @@ def main():
             "value": world * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
+                      "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": args.batch, "parallelism": f"replicas x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if args.precision == "f32" else "conv3_igemm_bf16s",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": traffic if args.precision == "f32" else None,
+                         "mfma_passes_per_product": PASSES[args.precision],
+                         "executed_frac": achieved * PASSES[args.precision] / peak,
                          "algorithmic_flops_per_launch": alg_conv3 / max(conv_launches, 1),
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,

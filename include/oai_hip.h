@@ -114,6 +114,17 @@ typedef struct oai_layer_params {
 int oai_unet_create(const oai_layer_params layers_host[OAI_UNET_NUM_LAYERS], float bn_eps, oai_unet** out);
 void oai_unet_destroy(oai_unet* h);
 
+/* Arithmetic of the 3x3x3 conv layers (everything else is always fp32):
+ *   OAI_PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products, the default.
+ *   OAI_PREC_BF16X6  every fp32 operand split into 3 bf16 terms, 6 bf16 MFMA passes per product: fp32-grade
+ *                    results (dropped terms are O(2^-24)) at 2.7x the fp32 MFMA rate.
+ *   OAI_PREC_BF16X3  2 terms, 3 passes: ~2^-17 relative error per product, 5.3x the fp32 MFMA rate.
+ * Activations stay fp32 in memory in every mode. */
+#define OAI_PREC_F32 0
+#define OAI_PREC_BF16X3 1
+#define OAI_PREC_BF16X6 2
+int oai_unet_set_precision(oai_unet* h, int mode);
+
 /* Bytes of device scratch oai_unet_forward_* needs for `batch` tiles of (td,th,tw). */
 size_t oai_unet_workspace_bytes(const oai_unet* h, int td, int th, int tw, int batch);
 

@@ -1,7 +1,9 @@
 // Host side of the segmentation path: weight ingest (reference layouts -> MFMA panels),
 // workspace planning, the layer schedule of UNet.forward (networks.py:109-149) with the
 // bit-identical dead-output trim, and the C ABI.
+#include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -17,6 +19,8 @@ struct Layer {
     int kind = 0, cin = 0, cout = 0;
     int c0 = 0, c1 = 0;                 // concat split of cin (c1 = skip channels)
     float4* panel = nullptr;            // MFMA weight panel (kinds 0,1,2 except ec0)
+    float4* panel_bf[2] = {nullptr, nullptr};   // split-bf16 panels of the k3 layers, NS = 2 / 3 (built on demand)
+    std::vector<float> wk_host;         // canonical [27][cin][cout] weights of the k3 layers (for re-packing)
     float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
     float* scale = nullptr;
     float* shift = nullptr;
@@ -27,6 +31,7 @@ struct Layer {
 struct oai_unet {
     oai::Layer L[18];
     int variant = 0;                    // 0: MREP4/KC8, 1: MREP2/KC16
+    int precision = OAI_PREC_F32;
     int n_classes = 0;
     std::vector<void*> allocs;
     bool profile = false;
@@ -72,6 +77,51 @@ static std::vector<float> pack_conv3_panel(const std::vector<float>& wk, int C0,
                                 const int cl = cl0 + kg * 8 + 4 * (lane >> 5) + s;
                                 const int co = cb * 64 + nr * 32 + (lane & 31);
                                 if (cl < Csrc && co < Cout) out[o] = wk[((size_t)t * Cin + cofs + cl) * Cout + co];
+                            }
+        }
+    return out;
+}
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Split-bf16 panel of conv3_igemm_bf16s: [cb][chunk of 16][tap][term][nr][lane] x 8 bf16, where lane (half h, column j)
+// holds channels 8h..8h+7 of the chunk for cout cb*64+nr*32+j.  Terms: w = t0 + t1 (+ t2), each the RNE bf16 of the rest.
+static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int C0, int C1, int Cout, int NS) {
+    const int Cin = C0 + C1, KC = 16;
+    const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+    const size_t units = ((size_t)ncb * (nch0 + nch1) * 27 + 1) * NS * 2 * 64;      // 16-byte units, +1 tap of prefetch slack
+    std::vector<float> out(units * 4, 0.0f);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+    size_t u = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nch0 + nch1; ++ch) {
+            const bool first = ch < nch0;
+            const int Csrc = first ? C0 : C1, cofs = first ? 0 : C0, cl0 = (first ? ch : ch - nch0) * KC;
+            for (int t = 0; t < 27; ++t)
+                for (int k = 0; k < NS; ++k)
+                    for (int nr = 0; nr < 2; ++nr)
+                        for (int lane = 0; lane < 64; ++lane, ++u)
+                            for (int j = 0; j < 8; ++j) {
+                                const int cl = cl0 + 8 * (lane >> 5) + j;
+                                const int co = cb * 64 + nr * 32 + (lane & 31);
+                                if (cl < Csrc && co < Cout) {
+                                    float r = wk[((size_t)t * Cin + cofs + cl) * Cout + co];
+                                    uint16_t b = 0;
+                                    for (int kk = 0; kk <= k; ++kk) { b = f32_to_bf16_rne(r); r -= bf16_to_f32(b); }
+                                    o16[u * 8 + j] = b;
+                                }
                             }
         }
     return out;
@@ -160,7 +210,8 @@ template <int MREP, int KC, int RX, int RY, int WY, int WX>
 static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
     if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
-    a.nbz = cdiv(box.hi[0] - box.lo[0], MREP);
+    const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split-bf16 kernels use 2 z slices per block
+    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? 2 : MREP);
     a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
     a.nbx = cdiv(box.hi[2] - box.lo[2], WX * RX);
     const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
@@ -175,7 +226,9 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-    conv3_igemm_f32<MREP, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    else if (KC == 8 && h->precision == OAI_PREC_BF16X6) conv3_igemm_bf16s<3, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    else conv3_igemm_f32<MREP, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
     if (h->profile) {
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
@@ -190,7 +243,8 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
                         const int dims[3], const Box& box, int ntiles, hipStream_t st) {
     ConvArgs a;
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
-    a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
+    a.out = out; a.Cout = L.cout; a.scale = L.scale; a.shift = L.shift;
+    a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : 1];
     a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
     a.ncb = (L.cout + 63) / 64;
     a.relu = 1;
@@ -362,8 +416,8 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
             std::vector<float> wk = canonical_k3(p);          // [27][1][cout]
             rc = upload(h, wk, &L.plain);
         } else if (p.kind == 0 || p.kind == 1) {
-            std::vector<float> wk = canonical_k3(p);
-            rc = upload(h, pack_conv3_panel(wk, L.c0, L.c1, p.cout, KC), &L.panel);
+            L.wk_host = canonical_k3(p);
+            rc = upload(h, pack_conv3_panel(L.wk_host, L.c0, L.c1, p.cout, KC), &L.panel);
         } else if (p.kind == 2) {
             rc = upload(h, pack_up_panel(p), &L.panel);
         } else {
@@ -373,6 +427,22 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
     }
     if (rc != OAI_OK) { oai_unet_destroy(h); return rc; }
     *out = h;
+    return OAI_OK;
+}
+
+int oai_unet_set_precision(oai_unet* h, int mode) {
+    OAI_CHECK_ARG(h, "oai_unet_set_precision: null handle");
+    OAI_CHECK_ARG(mode == OAI_PREC_F32 || mode == OAI_PREC_BF16X3 || mode == OAI_PREC_BF16X6, "oai_unet_set_precision: unknown mode %d", mode);
+    OAI_CHECK_ARG(mode == OAI_PREC_F32 || h->variant == 0, "oai_unet_set_precision: split-bf16 needs OAI_CONV_VARIANT=0");
+    if (mode != OAI_PREC_F32) {
+        const int slot = mode == OAI_PREC_BF16X3 ? 0 : 1, NS = slot + 2;
+        for (int k = 1; k < 17; ++k) {
+            Layer& L = h->L[k];
+            if ((L.kind != 0 && L.kind != 1) || L.panel_bf[slot]) continue;
+            if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS), &L.panel_bf[slot])) return rc;
+        }
+    }
+    h->precision = mode;
     return OAI_OK;
 }
 

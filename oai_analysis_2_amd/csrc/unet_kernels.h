@@ -193,6 +193,185 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bf16 variant of the same implicit GEMM on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).
+//
+// Every fp32 operand x is split into NS bf16 terms x = x0 + x1 (+ x2) (+ O(2^-8NS) residual), each term the
+// round-to-nearest bf16 of what the previous terms left; a product a*b is the sum of the term products whose
+// combined order is < NS:  NS=2 -> a0b0 + a0b1 + a1b0            (3 MFMA passes, error ~2^-17 per product)
+//                          NS=3 -> + a0b2 + a2b0 + a1b1           (6 MFMA passes, error ~2^-24: fp32 grade)
+// Products are exact in the MFMA and accumulated in fp32, so NS=3 reproduces the fp32 kernel to fp32 rounding
+// noise while issuing 6 x 32 cycles per 16-deep k step instead of 8 x 64.
+// Activations stay fp32 in HBM: the split happens once per halo voxel when the chunk is staged into LDS (27x
+// reuse); weights are split on the host at ingest.  Same tile shapes, same epilogue as conv3_igemm_f32.
+// ---------------------------------------------------------------------------------------------
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int NS>
+__device__ __forceinline__ void split_bf16(const float4 v, bf16x4 (&t)[NS]) {
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 b = (__bf16)r[j];            // round to nearest even (v_cvt_pk_bf16_f32)
+            t[k][j] = b;
+            r[j] -= (float)b;                           // exact in fp32
+        }
+}
+
+template <int NS, int MREP, int RX, int RY, int WY, int WX>
+__global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
+    static_assert(RX * RY == 32 && WY * WX == 4 && (NS == 2 || NS == 3), "bad configuration");
+    constexpr int KC = 16, NREP = 2, Q = 4;
+    constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2;
+    constexpr int TZ = MREP, HZ = TZ + 2;
+    constexpr int REC = NS == 2 ? 80 : 96;            // bytes per halo voxel: NS x 16 bf16 (+16 pad when it fits)
+    constexpr int HVOX = HZ * HY * HX;
+    constexpr int NSLOT = (HVOX * Q + 255) / 256;
+    constexpr int NPASS = NS == 2 ? 3 : 6;
+    constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HVOX * REC];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = blockIdx.x;
+    const int cb = id % a.ncb; id /= a.ncb;
+    const int bx = id % a.nbx; id /= a.nbx;
+    const int by = id % a.nby; id /= a.nby;
+    const int bz = id % a.nbz; id /= a.nbz;
+    const int tile = id;
+    const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * kTY, ox0 = a.lo[2] + bx * kTX;
+    const int mvalid = min(MREP, a.hi[0] - oz0);
+
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int row = lane & 31, half = lane >> 5;
+    const int wy = wave / WX, wx = wave % WX;
+    const int lx = wx * RX + row % RX, ly = wy * RY + row / RX;
+    const unsigned char* a_ptr = &lds[(ly * HX + lx) * REC + 16 * half];
+
+    const int nch0 = (a.C0 + KC - 1) / KC, nch1 = (a.C1 + KC - 1) / KC;
+    const int nchunks = nch0 + nch1;
+    constexpr int STEP = NS * NREP * 64;               // float4 (16-byte) units of weights per tap
+    const float4* wp = a.wpanel + (size_t)cb * nchunks * 27 * STEP + lane;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+
+    float4 hreg[NSLOT];
+    auto halo_load = [&](int ch) {
+        const bool first = ch < nch0;
+        const float* src = first ? a.src0 : a.src1;
+        const int C = first ? a.C0 : a.C1;
+        const int c0 = (first ? ch : ch - nch0) * KC;
+        const float* sbase = src + (size_t)tile * plane * C + c0;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int slot = tid + i * 256;
+            const int hv = slot / Q, q = slot - hv * Q;
+            const int hx = hv % HX;
+            const int t2 = hv / HX;
+            const int hy = t2 % HY, hz = t2 / HY;
+            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < HVOX * Q && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H &&
+                (unsigned)gx < (unsigned)a.W && c0 + 4 * q < C)
+                v = *reinterpret_cast<const float4*>(sbase + (((size_t)gz * a.H + gy) * a.W + gx) * C + 4 * q);
+            hreg[i] = v;
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int slot = tid + i * 256;
+            const int hv = slot / Q, q = slot - hv * Q;
+            if (slot < HVOX * Q) {
+                bf16x4 t[NS];
+                split_bf16<NS>(hreg[i], t);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<bf16x4*>(&lds[hv * REC + k * 32 + q * 8]) = t[k];
+            }
+        }
+    };
+
+    float4 bcur[NS][NREP], bnext[NS][NREP];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bcur[k][n] = wp[(k * NREP + n) * 64];
+    wp += STEP;
+    halo_load(0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        halo_store();
+        __syncthreads();
+        if (ch + 1 < nchunks) halo_load(ch + 1);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            float4 acur[NS][MREP];
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int m = 0; m < MREP; ++m)
+                    acur[k][m] = *reinterpret_cast<const float4*>(a_ptr + (((m + dz) * HY + dy) * HX + dx) * REC + k * 32);
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
+            wp += STEP;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) {
+                    if (m < mvalid) {
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, acur[PA[p]][m]), __builtin_bit_cast(bf16x8, bcur[PB[p]][n]),
+                                acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
+        }
+    }
+
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = cb * 64 + n * 32 + row;
+        if (co >= a.Cout) continue;
+        const float sc = a.scale[co], sh = a.shift[co];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            const int oz = oz0 + m;
+            if (oz >= a.hi[0]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ox = ox0 + wx * RX + rr % RX, oy = oy0 + wy * RY + rr / RX;
+                if (ox < a.hi[2] && oy < a.hi[1]) {
+                    float v = acc[m][n][r] * sc + sh;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    a.out[((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ConvTranspose3d(k=2, s=2): out[2i+a][2j+b][2k+c][co] = sum_ci x[i][j][k][ci] * W[ci][co][a][b][c]
 // (networks.py:56,59,62).  One GEMM with M = input voxels, K = cin, N = 8*cout (column n =
 // parity*cout + co), the store scatters each column to its parity's output voxel.

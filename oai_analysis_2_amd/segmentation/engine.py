@@ -35,7 +35,9 @@ def tile_grid(size_zyx: Sequence[int], tile_zyx: Sequence[int], overlap_zyx: Seq
 class UNetEngine:
     """The reference ``UNet`` (networks.py:38-149) as a resident set of packed weights on the GPU."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device=None, bn_eps: float = BN_EPS):
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device=None, bn_eps: float = BN_EPS, precision: str = "f32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.OaiError("no HIP device: the MI355X path has no CPU fallback")
@@ -82,6 +84,17 @@ class UNetEngine:
             _lib.check(self.lib.oai_unet_create(params, C.c_float(bn_eps), C.byref(handle)), "oai_unet_create")
         self._h = handle
         self._ws: Optional[torch.Tensor] = None
+        self.precision = "f32"
+        if precision != "f32":
+            self.set_precision(precision)
+
+    def set_precision(self, precision: str) -> None:
+        """Arithmetic of the 3x3x3 conv layers: "f32" (exact fp32 MFMA), "bf16x6" (fp32-grade split), "bf16x3"."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_set_precision(self._h, self.PRECISIONS[precision]), "oai_unet_set_precision")
+        self.precision = precision
 
     def __del__(self):
         h = getattr(self, "_h", None)
