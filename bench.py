@@ -66,7 +66,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per U-Net pass (sizes the activation workspace)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"],
                     help="arithmetic of the 3x3x3 conv layers: exact fp32 MFMA, or split-bf16 with 6 / 3 MFMA passes")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "tileshard"],
+                    help="N>1: replicas = one volume per rank per step (weak scaling, no collective); tileshard = every step "
+                         "is ONE volume whose 160 tiles are split over the ranks + one RCCL all_gather (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x6 measurement reported beside the fp32 one")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,6 +87,7 @@ def main():
 
     from oai_analysis_2_amd import _lib
     from oai_analysis_2_amd.image import Image
+    from oai_analysis_2_amd.parallel import tile_range_for_rank
     from oai_analysis_2_amd.pipeline import OVERLAP_ZYX, TILE_ZYX, VolumePipeline
     from oai_analysis_2_amd.registration import IconEngine
     from oai_analysis_2_amd.segmentation.engine import UNetEngine, tile_grid
@@ -96,11 +101,13 @@ def main():
     atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
     pipe = VolumePipeline(unet, icon, atlas, batch=args.batch)
     n_distinct = 2
-    vols_np = [make_volume(100 * rank + i, VOL_SHAPE) for i in range(n_distinct)]
+    vols_np = [make_volume((100 * rank if args.mode == "replicas" else 0) + i, VOL_SHAPE) for i in range(n_distinct)]
     vols = [torch.from_numpy(v).cuda() for v in vols_np]                  # resident in HBM before timing
     meta = Image(vols_np[0], [0.36, 0.36, 0.7], [2.0, -3.0, 1.0])
 
     def step(i):
+        if args.mode == "tileshard":
+            return pipe.run_sharded(vols[i % n_distinct], meta)
         return pipe.run(vols[i % n_distinct], meta)
 
     for i in range(args.warmup):
@@ -128,7 +135,8 @@ def main():
 
     if rank == 0:
         _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
-        alg_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles * args.steps    # this rank's volumes
+        my_tiles = n_tiles if args.mode == "replicas" else len(range(*tile_range_for_rank(n_tiles, rank, world)))
+        alg_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * my_tiles * args.steps    # this rank's tiles
         achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
         traffic = None            # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
@@ -139,14 +147,14 @@ def main():
             pass
         out = {
             "metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32",
-            "value": world * args.steps / dt, "unit": "volumes/s",
+            "value": (world if args.mode == "replicas" else 1) * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
                       "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
-                       "tiles_per_pass": args.batch, "parallelism": f"replicas x{world}"},
+                       "tiles_per_pass": args.batch, "parallelism": f"{args.mode} x{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if args.precision == "f32" else "conv3_igemm_bf16s",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic if args.precision == "f32" else None,
@@ -156,6 +164,28 @@ def main():
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
         }
+        if world == 1 and args.precision == "f32" and not args.no_alt:
+            # the same workload with the fp32-grade split-bf16 conv kernels (6 MFMA passes per product); reported beside
+            # the primary fp32 number, never as `value`
+            unet.set_precision("bf16x6")
+            step(0)
+            torch.cuda.synchronize()
+            unet.profile(True)
+            ta = time.perf_counter()
+            n_alt = min(2, args.steps)
+            for i in range(n_alt):
+                step(i)
+            torch.cuda.synchronize()
+            dta = time.perf_counter() - ta
+            ms_a, n_a = unet.profile_read()
+            unet.profile(False)
+            unet.set_precision("f32")
+            ach = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles * n_alt / (ms_a * 1e-3) / 1e12
+            out["alt_precision"] = {"precision": "bf16x6", "value": n_alt / dta, "unit": "volumes/s", "ms_per_step": 1e3 * dta / n_alt,
+                                    "roofline": {"bound": "mfma", "kernel": "conv3_igemm_bf16s", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                 "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "mfma_passes_per_product": 6,
+                                                 "executed_frac": 6 * ach / MFMA_BF16_PEAK_TFLOPS},
+                                    "parity": "same gates as f32 (tests/test_unet_gpu.py: logits <= 1e-4 rel, sum|dp| < 12 per 23.6M voxels)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vols_np[0], meta, atlas, unet_sd, icon_sd)
         print(json.dumps(out), flush=True)

@@ -60,6 +60,22 @@ class VolumePipeline:
         b2n, n2a = resample_affines(meta_A, self.atlas, self.icon.net_shape)
         return [ops.resample_through_disp(maps[c], disp, b2n, n2a, self.atlas.array.shape) for c in range(maps.shape[0])]
 
+    def segment_sharded(self, vol: torch.Tensor, group=None) -> torch.Tensor:
+        """One volume split over the ranks of ``group`` at tile granularity: every rank runs the U-Net on
+        its contiguous tile range, ONE all_gather (RCCL) gives every rank all kept-centre blocks, then stitch."""
+        from . import parallel
+        _, _, n_tiles = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
+        blocks = parallel.segment_tile_sharded(
+            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch), n_tiles, group)
+        return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
+
+    def run_sharded(self, vol: torch.Tensor, meta_A: Image, group=None) -> VolumeResult:
+        """Single-volume latency mode: segmentation tile-sharded, registration + resample replicated (0.1 TFLOP)."""
+        maps = self.segment_sharded(vol, group)
+        phi = self.register(vol)
+        fc_a, tc_a = self.resample(maps, phi, meta_A)
+        return VolumeResult(maps[0], maps[1], phi, fc_a, tc_a)
+
     def run(self, vol: torch.Tensor, meta_A: Image) -> VolumeResult:
         maps = self.segment(vol)
         phi = self.register(vol)

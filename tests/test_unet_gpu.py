@@ -127,3 +127,54 @@ def test_bf16x3_prob_maps_within_the_north_star_tolerance(golden_dir):
     for got, ref, prob in ((masks[0], z["fc_mask"], z["fc_prob"]), (masks[1], z["tc_mask"], z["tc_prob"])):
         diff = got.astype(np.uint8) != ref
         assert np.all(np.abs(prob[diff] - 0.5) < 1e-4)
+
+
+@pytest.mark.parametrize("shape,patch,ovl", [((21, 45, 38), (32, 32, 16), (8, 8, 4)),      # ragged: hi padding != overlap
+                                             ((9, 20, 70), (32, 16, 8), (4, 2, 1)),        # reflect pad wider than the tile centre
+                                             ((16, 32, 32), (32, 32, 16), (8, 8, 4))])     # exactly one tile's centre... plus frame
+def test_segment_ragged_volumes_vs_oracle(shape, patch, ovl):
+    """Partition edge cases of image_transforms.py:407-415 on the gather-fused path (no golden: oracle is pinned)."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = make_unet_state_dict(seed=7, width_div=4)
+    vol = make_volume(3, shape)
+    fc_ref, tc_ref = oseg.segment(vol, sd, patch, ovl, output_prob=True)
+    eng = UNetEngine(sd)
+    tile_zyx, ovl_zyx, crop_zyx = patch[::-1], ovl[::-1], (ovl[2], ovl[0], ovl[1])
+    blocks = eng.segment_tiles(torch.from_numpy(vol).cuda(), tile_zyx, ovl_zyx, out_mode=0, batch=5)
+    maps = eng.stitch(blocks, shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
+    assert np.abs(maps[0] - fc_ref).max() < 1e-5 and np.abs(maps[1] - tc_ref).max() < 1e-5
+    assert maps[0][:crop_zyx[0]].max() == 0 and maps[0][:, :, -crop_zyx[2]:].max() == 0      # the zeroed frame
+
+
+def test_bad_arguments_raise():
+    from oai_analysis_2_amd import _lib
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    eng = UNetEngine(make_unet_state_dict(seed=7, width_div=4))
+    v = torch.zeros((16, 32, 32), device="cuda")
+    with pytest.raises(_lib.OaiError, match="multiple of 8"):
+        eng.segment_tiles(v, (12, 32, 32), (2, 8, 8))
+    with pytest.raises(ValueError, match="overlap"):
+        eng.segment_tiles(v, (16, 32, 32), (8, 8, 8))
+    with pytest.raises(_lib.OaiError, match="tile range"):
+        eng.segment_tiles(v, (16, 32, 32), (4, 8, 8), (0, 99))
+    with pytest.raises(ValueError):
+        eng.set_precision("fp8")
+    sd = make_unet_state_dict(seed=7, width_div=4)
+    sd.pop("dc4.0.weight")
+    with pytest.raises(KeyError, match="dc4.0.weight"):                 # strict load, utils.py:29
+        UNetEngine(sd)
+
+
+def test_sharded_pipeline_equals_unsharded_on_one_rank():
+    """world_size 1 through the same code path the multi-GPU tile shard uses (collective logic: tests/test_parallel_cpu.py)."""
+    from oai_analysis_2_amd.image import Image
+    from oai_analysis_2_amd.pipeline import VolumePipeline
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    from oai_analysis_2_amd.synth import make_icon_state_dict
+    shape, net = (24, 72, 72), (40, 48, 48)
+    pipe = VolumePipeline(UNetEngine(make_unet_state_dict(1, width_div=2)), IconEngine(make_icon_state_dict(1, 0.1), net_shape=net),
+                          Image(make_volume(10, shape)), tile_zyx=(16, 32, 32), overlap_zyx=(4, 8, 8), crop_zyx=(4, 8, 8), batch=8)
+    vol = torch.from_numpy(make_volume(11, shape)).cuda()
+    a, b = pipe.run(vol, Image(vol.cpu().numpy())), pipe.run_sharded(vol, Image(vol.cpu().numpy()))
+    assert torch.equal(a.fc, b.fc) and torch.equal(a.tc_atlas, b.tc_atlas)
