@@ -21,41 +21,63 @@ constexpr int kUpOut[5] = {16, 32, 64, 128, 256};
 constexpr int kUpIn[5] = {48, 96, 192, 512, 512};
 constexpr float kLeaky = 0.01f;
 constexpr float kBnEps = 1e-5f;
+constexpr long long kSplitKBelow = 16384;     // output voxels (per launch / per parity class) below which K is split over threads
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : v * kLeaky; }
 
 // Conv3d k3 p1, stride S, on leaky_relu(x) (PRE) + bias, optional residual
 //   RES: + avg_pool3d(x,2,ceil_mode=True) zero-padded IN FRONT to Cout channels (UNet2 down path)
 // out = (acc + bias [+ res]) / div
-template <int S, int COUT_T, bool PRE, bool RES>
+// KS > 1 (deep levels, a few hundred voxels or fewer but K = 27*Cin up to 6912): the block's 256 threads are
+// 256/KS voxels x KS slices of the input channels; partial sums meet in LDS and slice 0 runs the epilogue.
+template <int S, int COUT_T, bool PRE, bool RES, int KS>
 __global__ void __launch_bounds__(256)
 icon_conv3_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                   const float* __restrict__ wk /*[Cin][27][Cout]*/, const float* __restrict__ bias,
                   float* __restrict__ out, int Cout, int Do, int Ho, int Wo, float div) {
+    constexpr int VT = 256 / KS;
+    __shared__ float red[KS > 1 ? (KS - 1) * VT * COUT_T : 1];
     const int cg = blockIdx.y;
+    const int ks = KS == 1 ? 0 : threadIdx.x / VT;      // literal 0 keeps the channel loop wave-uniform when K is not split
     const long long nvox = (long long)Do * Ho * Wo;
-    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= nvox) return;
-    const int ox = (int)(v % Wo), oy = (int)((v / Wo) % Ho), oz = (int)(v / ((long long)Wo * Ho));
+    const long long v = (long long)blockIdx.x * VT + threadIdx.x % VT;
+    const bool live = v < nvox;
+    const long long vv = live ? v : 0;
+    const int ox = (int)(vv % Wo), oy = (int)((vv / Wo) % Ho), oz = (int)(vv / ((long long)Wo * Ho));
     const long long plane = (long long)D * H * W;
     float acc[COUT_T];
 #pragma unroll
     for (int j = 0; j < COUT_T; ++j) acc[j] = 0.0f;
     const int iz0 = oz * S - 1, iy0 = oy * S - 1, ix0 = ox * S - 1;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float* xp = x + ci * plane;
-        const float* wp = wk + ((long long)ci * 27) * Cout + cg * COUT_T;
+    if (KS == 1 && !live) return;                 // (with KS > 1 every thread must reach the barrier)
+    if (KS == 1 || live)
+        for (int ci = ks; ci < Cin; ci += KS) {
+            const float* xp = x + ci * plane;
+            const float* wp = wk + ((long long)ci * 27) * Cout + cg * COUT_T;
 #pragma unroll 3
-        for (int t = 0; t < 27; ++t) {
-            const int iz = iz0 + t / 9, iy = iy0 + (t / 3) % 3, ix = ix0 + t % 3;
-            float in = 0.0f;
-            if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                in = xp[((long long)iz * H + iy) * W + ix];
-            if (PRE) in = leaky(in);
+            for (int t = 0; t < 27; ++t) {
+                const int iz = iz0 + t / 9, iy = iy0 + (t / 3) % 3, ix = ix0 + t % 3;
+                float in = 0.0f;
+                if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    in = xp[((long long)iz * H + iy) * W + ix];
+                if (PRE) in = leaky(in);
 #pragma unroll
-            for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(in, wp[t * Cout + j], acc[j]);
+                for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(in, wp[t * Cout + j], acc[j]);
+            }
         }
+    if (KS > 1) {
+        if (ks > 0) {
+#pragma unroll
+            for (int j = 0; j < COUT_T; ++j) red[((ks - 1) * COUT_T + j) * VT + threadIdx.x % VT] = acc[j];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k)              // fixed order: deterministic
+#pragma unroll
+            for (int j = 0; j < COUT_T; ++j) acc[j] += red[((k - 1) * COUT_T + j) * VT + threadIdx.x];
     }
+    if (!live) return;
 #pragma unroll
     for (int j = 0; j < COUT_T; ++j) {
         const int co = cg * COUT_T + j;
@@ -87,19 +109,23 @@ __device__ __forceinline__ void up_src(int dst, int in_size, int& i0, int& i1, f
 
 // ConvTranspose3d k4 s2 p1 on leaky_relu(x) + bias + trilinear-x2 upsample of x[:Cout] -> BatchNorm (eval)
 // -> cropped to (Dc,Hc,Wc).  One block = one output parity class (uniform weights).
-template <int COUT_T>
+template <int COUT_T, int KS>
 __global__ void __launch_bounds__(256)
 icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                const float* __restrict__ wk /*[Cin][64][Cout]*/, const float* __restrict__ bias,
                const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
                float* __restrict__ out, int Cout, int Dc, int Hc, int Wc) {
+    constexpr int VT = 256 / KS;
+    __shared__ float red[KS > 1 ? (KS - 1) * VT * COUT_T : 1];
     const int cg = blockIdx.y;
+    const int ks = KS == 1 ? 0 : threadIdx.x / VT;      // literal 0 keeps the channel loop wave-uniform when K is not split
     const int par = blockIdx.z, pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
     const int nz = (Dc - pz + 1) / 2, ny = (Hc - py + 1) / 2, nx = (Wc - px + 1) / 2;
     const long long nv = (long long)nz * ny * nx;
-    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= nv) return;
-    const int tx = (int)(v % nx), ty = (int)((v / nx) % ny), tz = (int)(v / ((long long)nx * ny));
+    const long long v = (long long)blockIdx.x * VT + threadIdx.x % VT;
+    const bool live = v < nv;
+    const long long vv = live ? v : 0;
+    const int tx = (int)(vv % nx), ty = (int)((vv / nx) % ny), tz = (int)(vv / ((long long)nx * ny));
     const int oz = 2 * tz + pz, oy = 2 * ty + py, ox = 2 * tx + px;
     const long long plane = (long long)D * H * W;
     const long long oplane = (long long)Dc * Hc * Wc;
@@ -108,21 +134,36 @@ icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
     float acc[COUT_T];
 #pragma unroll
     for (int j = 0; j < COUT_T; ++j) acc[j] = 0.0f;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float* xp = x + ci * plane;
-        const float* wp = wk + ((long long)ci * 64) * Cout + cg * COUT_T;
+    if (KS == 1 && !live) return;
+    if (KS == 1 || live)
+        for (int ci = ks; ci < Cin; ci += KS) {
+            const float* xp = x + ci * plane;
+            const float* wp = wk + ((long long)ci * 64) * Cout + cg * COUT_T;
 #pragma unroll 2
-        for (int t = 0; t < 8; ++t) {
-            const int kz = qz + 2 * (t >> 2), ky = qy + 2 * ((t >> 1) & 1), kx = qx + 2 * (t & 1);
-            const int iz = (oz + 1 - kz) >> 1, iy = (oy + 1 - ky) >> 1, ix = (ox + 1 - kx) >> 1;
-            float in = 0.0f;
-            if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                in = leaky(xp[((long long)iz * H + iy) * W + ix]);
-            const float* w = wp + ((kz * 4 + ky) * 4 + kx) * Cout;
+            for (int t = 0; t < 8; ++t) {
+                const int kz = qz + 2 * (t >> 2), ky = qy + 2 * ((t >> 1) & 1), kx = qx + 2 * (t & 1);
+                const int iz = (oz + 1 - kz) >> 1, iy = (oy + 1 - ky) >> 1, ix = (ox + 1 - kx) >> 1;
+                float in = 0.0f;
+                if ((unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    in = leaky(xp[((long long)iz * H + iy) * W + ix]);
+                const float* w = wp + ((kz * 4 + ky) * 4 + kx) * Cout;
 #pragma unroll
-            for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(in, w[j], acc[j]);
+                for (int j = 0; j < COUT_T; ++j) acc[j] = fmaf(in, w[j], acc[j]);
+            }
         }
+    if (KS > 1) {
+        if (ks > 0) {
+#pragma unroll
+            for (int j = 0; j < COUT_T; ++j) red[((ks - 1) * COUT_T + j) * VT + threadIdx.x % VT] = acc[j];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k)
+#pragma unroll
+            for (int j = 0; j < COUT_T; ++j) acc[j] += red[((k - 1) * COUT_T + j) * VT + threadIdx.x];
     }
+    if (!live) return;
     int z0, z1, y0, y1, x0, x1;
     float a0, a1, b0, b1, c0, c1;
     up_src(oz, D, z0, z1, a0, a1);
@@ -217,23 +258,37 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
     for (int l = 0; l < 5; ++l) {
         const float* src = cat[l] + (size_t)kUpOut[l] * dm.vox[l];
         float* dst = l < 4 ? cat[l + 1] + (size_t)kUpOut[l + 1] * dm.vox[l + 1] : bottom;
-        dim3 grid(oai::cdiv(dm.vox[l + 1], 256), kDown[l + 1] / 16);
-        icon_conv3_kernel<2, 16, true, true><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
-                                                                    nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
-                                                                    dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+        if (dm.vox[l + 1] >= kSplitKBelow || kDown[l] < 8) {
+            dim3 grid(oai::cdiv(dm.vox[l + 1], 256), kDown[l + 1] / 16);
+            icon_conv3_kernel<2, 16, true, true, 1><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
+                                                                           nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
+                                                                           dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+        } else {
+            dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1] / 16);
+            icon_conv3_kernel<2, 16, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
+                                                                           nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
+                                                                           dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+        }
         OAI_CHECK_LAUNCH();
     }
     for (int l = 4; l >= 0; --l) {
         const float* src = l == 4 ? bottom : cat[l + 1];
         const long long per_par = (long long)((dm.d[l][0] + 1) / 2) * ((dm.d[l][1] + 1) / 2) * ((dm.d[l][2] + 1) / 2);
-        dim3 grid(oai::cdiv(per_par, 256), kUpOut[l] / 16, 8);
-        icon_up_kernel<16><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
-                                                  nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
-                                                  dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        if (per_par >= kSplitKBelow) {
+            dim3 grid(oai::cdiv(per_par, 256), kUpOut[l] / 16, 8);
+            icon_up_kernel<16, 1><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                         nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                         dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        } else {
+            dim3 grid(oai::cdiv(per_par, 32), kUpOut[l] / 16, 8);
+            icon_up_kernel<16, 8><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                         nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                         dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        }
         OAI_CHECK_LAUNCH();
     }
     dim3 grid(oai::cdiv(dm.vox[0], 256), 1);
-    icon_conv3_kernel<1, 3, false, false><<<grid, 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W, nw.last_w, nw.last_b,
+    icon_conv3_kernel<1, 3, false, false, 1><<<grid, 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W, nw.last_w, nw.last_b,
                                                                  out, 3, D, H, W, 10.0f);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
