@@ -83,6 +83,16 @@ int oai_resample_through_disp(const float* prob_dev, int nzA, int nyA, int nxA,
                               float* out_dev, int nzB, int nyB, int nxB, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Intensity windowing, the step just before the hot path: image_normalize(image, lo, hi, omin, omax) of
+ * oai_analysis/dask_processing.py:10-26 (called with 0.1, 99.9, 0, 1 at :75 and :177) =
+ * np.percentile window (exact order statistics, numpy float32 interpolation) + itk.IntensityWindowingImageFilter.
+ * window_out_dev (optional, 2 floats on the device) receives (window_min, window_max).
+ * ---------------------------------------------------------------------------------------- */
+size_t oai_image_normalize_workspace_bytes(void);
+int oai_image_normalize(const float* in_dev, size_t n, float pct_lo, float pct_hi, float out_min, float out_max,
+                        float* out_dev, float* window_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Segmentation.  Replaces `self.model(temp_input.to(self.device)).cpu()` and the code around
  * it in Segmenter3DInPatchClassWise.segment (oai_analysis/segmentation/segmenter.py:100-131):
  * Partition.__call__ (image_transforms.py:395-455), UNet.forward (networks.py:109-149),

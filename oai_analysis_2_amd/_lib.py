@@ -45,6 +45,8 @@ SIGNATURES = {
     "oai_phi_to_itk_displacement": (_I, [_P, _I, _I, _I, _P, _P]),
     "oai_resample_through_disp": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
                                        _P, _I, _I, _I, _P]),
+    "oai_image_normalize_workspace_bytes": (_Z, []),
+    "oai_image_normalize": (_I, [_P, _Z, _F, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "oai_unet_create": (_I, [C.POINTER(LayerParams), _F, C.POINTER(_P)]),
     "oai_unet_destroy": (None, [_P]),
     "oai_unet_set_precision": (_I, [_P, _I]),

@@ -110,3 +110,17 @@ def resample_through_disp(prob: torch.Tensor, disp: torch.Tensor, b_index_to_net
                                              C.byref(a1), C.byref(a2), out.data_ptr(), nzB, nyB, nxB, _stream()),
                "oai_resample_through_disp")
     return out
+
+
+def image_normalize(vol: torch.Tensor, window_min_perc: float = 0.1, window_max_perc: float = 99.9,
+                    output_min: float = 0.0, output_max: float = 1.0, return_window: bool = False):
+    """``image_normalize`` of oai_analysis/dask_processing.py:10-26 on the device (fp32 image)."""
+    lib = _lib.load()
+    vol = _chk(vol, "vol")
+    out = torch.empty_like(vol)
+    ws = torch.empty(int(lib.oai_image_normalize_workspace_bytes()), dtype=torch.uint8, device=vol.device)
+    win = torch.empty(2, dtype=torch.float32, device=vol.device)
+    _lib.check(lib.oai_image_normalize(vol.data_ptr(), vol.numel(), float(window_min_perc), float(window_max_perc),
+                                       float(output_min), float(output_max), out.data_ptr(), win.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream()), "oai_image_normalize")
+    return (out, win) if return_window else out
