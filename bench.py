@@ -88,7 +88,7 @@ def main():
     from oai_analysis_2_amd import _lib
     from oai_analysis_2_amd.image import Image
     from oai_analysis_2_amd.parallel import tile_range_for_rank
-    from oai_analysis_2_amd.pipeline import OVERLAP_ZYX, TILE_ZYX, VolumePipeline
+    from oai_analysis_2_amd.pipeline import CROP_ZYX, OVERLAP_ZYX, TILE_ZYX, VolumePipeline
     from oai_analysis_2_amd.registration import IconEngine
     from oai_analysis_2_amd.segmentation.engine import UNetEngine, tile_grid
     from oai_analysis_2_amd.synth import make_icon_state_dict, make_unet_state_dict, make_volume
@@ -135,8 +135,11 @@ def main():
 
     if rank == 0:
         _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
-        my_tiles = n_tiles if args.mode == "replicas" else len(range(*tile_range_for_rank(n_tiles, rank, world)))
-        alg_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * my_tiles * args.steps    # this rank's tiles
+        my_frac = 1.0 if args.mode == "replicas" else len(range(*tile_range_for_rank(n_tiles, rank, world))) / n_tiles
+        # algorithmic FLOPs = what the stitched maps can depend on: per-layer trim boxes AND, per tile, only
+        # the part of the kept centre that assemble keeps (the zeroed 8/16/16 frame is dead output; SURVEY's 80.87 TFLOP ignores it)
+        vol_conv3 = unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, True)
+        alg_conv3 = vol_conv3 * my_frac * args.steps
         achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
         traffic = None            # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
@@ -162,7 +165,8 @@ def main():
                          "executed_frac": achieved * PASSES[args.precision] / peak,
                          "algorithmic_flops_per_launch": alg_conv3 / max(conv_launches, 1),
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
-            "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
+            "segment_algorithmic_tflop_per_volume": unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, False) / 1e12,
+            "segment_algorithmic_tflop_per_volume_survey_b1": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
         }
         if world == 1 and args.precision == "f32" and not args.no_alt:
             # the same workload with the fp32-grade split-bf16 conv kernels (6 MFMA passes per product); reported beside
@@ -180,7 +184,7 @@ def main():
             ms_a, n_a = unet.profile_read()
             unet.profile(False)
             unet.set_precision("f32")
-            ach = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles * n_alt / (ms_a * 1e-3) / 1e12
+            ach = vol_conv3 * n_alt / (ms_a * 1e-3) / 1e12
             out["alt_precision"] = {"precision": "bf16x6", "value": n_alt / dta, "unit": "volumes/s", "ms_per_step": 1e3 * dta / n_alt,
                                     "roofline": {"bound": "mfma", "kernel": "conv3_igemm_bf16s", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                                                  "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "mfma_passes_per_product": 6,

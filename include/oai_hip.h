@@ -148,9 +148,13 @@ int oai_unet_forward_tiles(oai_unet* h, const float* tiles_dev, float* logits_de
  * order: reflect-pad addressing of vol[D][H][W] (no tiles materialised) -> UNet on each tile ->
  * 1x1x1 head -> sigmoid (out_mode 0) or sigmoid>0.5 as 0/1 (out_mode 1) or raw logits (2) ->
  * kept centre blocks blocks_dev[tile - tile_begin][n_classes][ez][ey][ex] (e = tile - 2*overlap).
- * Only the region each layer needs for the kept centre is computed (bit-identical trim). */
+ * Only what the stitched result can depend on is computed (bit-identical dead-output trim): per layer the
+ * box its consumers need, and per tile only the part of the kept centre that
+ * Partition.assemble keeps -- crop_zyx (may be NULL) is the frame oai_stitch_blocks will zero, and the part
+ * beyond the image is trimmed.  Block voxels outside that part are left unwritten. */
 int oai_segment_tiles(oai_unet* h, const float* vol_dev, int D, int H, int W,
-                      const int tile_zyx[3], const int overlap_zyx[3], int tile_begin, int tile_end,
+                      const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
+                      int tile_begin, int tile_end,
                       int out_mode, float* blocks_dev, int batch,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
@@ -168,7 +172,11 @@ int oai_unet_profile_read(oai_unet* h, double* conv3_ms, long long* conv3_launch
 
 /* Algorithmic FLOPs (2*MACs) of one tile, full or with the dead-output trim. */
 double oai_unet_tile_flops(const oai_unet* h, int td, int th, int tw, const int overlap_zyx[3], int trimmed);
-/* Same, restricted to the layers the 3x3x3 implicit-GEMM kernel runs (ec1-ec7, dc8, dc7, dc5, dc4, dc2, dc1). */
+/* Algorithmic FLOPs of segmenting a whole D x H x W volume as oai_segment_tiles does it (per-tile boxes included);
+ * conv3_only restricts the sum to the layers of the 3x3x3 implicit-GEMM kernel. */
+double oai_unet_volume_flops(const oai_unet* h, int D, int H, int W, const int tile_zyx[3], const int overlap_zyx[3],
+                             const int crop_zyx[3], int trimmed, int conv3_only);
+/* Same as oai_unet_tile_flops, restricted to the layers the 3x3x3 implicit-GEMM kernel runs (ec1-ec7, dc8, dc7, dc5, dc4, dc2, dc1). */
 double oai_unet_tile_flops_conv3(const oai_unet* h, int td, int th, int tw, const int overlap_zyx[3], int trimmed);
 
 /* ------------------------------------------------------------------------------------------

@@ -52,7 +52,8 @@ SIGNATURES = {
     "oai_unet_set_precision": (_I, [_P, _I]),
     "oai_unet_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
     "oai_unet_forward_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
-    "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "oai_unet_volume_flops": (_D, [_P, _I, _I, _I, _I3, _I3, _I3, _I, _I]),
     "oai_stitch_blocks": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _I3, _P, _P]),
     "oai_unet_tile_flops": (_D, [_P, _I, _I, _I, _I3, _I]),
     "oai_unet_tile_flops_conv3": (_D, [_P, _I, _I, _I, _I3, _I]),

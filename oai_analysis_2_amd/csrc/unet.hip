@@ -12,7 +12,8 @@
 namespace oai {
 
 enum LayerId { EC0, EC1, EC2, EC3, EC4, EC5, EC6, EC7, DC9, DC8, DC7, DC6, DC5, DC4, DC3, DC2, DC1, DC0 };
-static const int kLevel[18] = {0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0};   // OUTPUT level
+__host__ __device__ static inline int layer_level(int k) { const int v[18] = {0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0}; return v[k]; }   // OUTPUT level
+__host__ __device__ static inline int layer_kind(int k) { const int v[18] = {0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 1, 2, 1, 1, 2, 1, 1, 3}; return v[k]; }
 static const int kKind[18] = {0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 1, 2, 1, 1, 2, 1, 1, 3};
 
 struct Layer {
@@ -159,13 +160,13 @@ static int upload(oai_unet* h, const std::vector<float>& v, T** dst) {
 
 struct Box { int lo[3], hi[3]; };
 
-static void full_box(Box& b, const int dims[3]) { for (int i = 0; i < 3; ++i) { b.lo[i] = 0; b.hi[i] = dims[i]; } }
+__host__ __device__ static void full_box(Box& b, const int dims[3]) { for (int i = 0; i < 3; ++i) { b.lo[i] = 0; b.hi[i] = dims[i]; } }
 
 // Output box each layer must produce so that the kept centre is unchanged (oracle/seg.py:trim_regions)
-static void plan_regions(const int tile[3], const int keep_lo[3], const int keep_hi[3], bool trimmed, Box need[18]) {
+__host__ __device__ static void plan_regions(const int tile[3], const int keep_lo[3], const int keep_hi[3], bool trimmed, Box need[18]) {
     int dims[4][3];
     for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) dims[l][i] = tile[i] >> l;
-    for (int k = 0; k < 18; ++k) full_box(need[k], dims[kLevel[k]]);
+    for (int k = 0; k < 18; ++k) full_box(need[k], dims[layer_level(k)]);
     for (int i = 0; i < 3; ++i) { need[DC0].lo[i] = keep_lo[i]; need[DC0].hi[i] = keep_hi[i]; }   // the head always crops
     if (!trimmed) return;
     auto grow = [&](const Box& b, int lvl) { Box r; for (int i = 0; i < 3; ++i) { r.lo[i] = b.lo[i] > 0 ? b.lo[i] - 1 : 0; r.hi[i] = b.hi[i] + 1 < dims[lvl][i] ? b.hi[i] + 1 : dims[lvl][i]; } return r; };
@@ -186,6 +187,8 @@ struct Plan {
     size_t off[24];
     size_t total;
 };
+constexpr int kMaxTilesPerTable = 4096;
+constexpr size_t kBoxTableBytes = ((size_t)18 * kMaxTilesPerTable * 6 * sizeof(int) + 255) / 256 * 256;
 enum Buf { B_E0, B_SYN0, B_P0, B_E2, B_SYN1, B_P1, B_E4, B_SYN2, B_P2, B_E6, B_E7, B_U9, B_D8, B_D7, B_U6, B_D5, B_D4, B_U3, B_D2, B_D1, B_COUNT };
 
 static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch) {
@@ -197,7 +200,7 @@ static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch)
         v2 * L[DC8].cout, v2 * L[DC7].cout, v1 * L[DC6].cout, v1 * L[DC5].cout, v1 * L[DC4].cout, v0 * L[DC3].cout,
         v0 * L[DC2].cout, v0 * L[DC1].cout};
     Plan p;
-    size_t o = 0;
+    size_t o = kBoxTableBytes;          // per-tile box table of the current oai_segment_tiles call lives at the start
     for (int i = 0; i < B_COUNT; ++i) {
         p.off[i] = o;
         o += ((sizes[i] * batch * sizeof(float) + 255) / 256) * 256;
@@ -207,7 +210,7 @@ static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch)
 }
 
 template <int MREP, int KC, int RX, int RY, int WY, int WX>
-static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
+static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {   // a.boxes set by the caller
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
     if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
     const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split-bf16 kernels use 2 z slices per block
@@ -240,8 +243,9 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
 // One conv layer = the main launch over the part of the output box that 8 x 16 (y, x) tiles cover exactly, plus up
 // to two thin remainder strips computed with tile shapes that fit them (trimmed boxes are e.g. 18 x 98 x 98).
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
-                        const int dims[3], const Box& box, int ntiles, hipStream_t st) {
+                        const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr) {
     ConvArgs a;
+    a.boxes = boxes;
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
     a.out = out; a.Cout = L.cout; a.scale = L.scale; a.shift = L.shift;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : 1];
@@ -278,8 +282,9 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
 }
 
 static int launch_up(const Layer& L, const float* src, float* out, const int in_dims[3], const Box& out_need,
-                     int ntiles, hipStream_t st) {
+                     int ntiles, hipStream_t st, const int* in_boxes = nullptr) {
     UpArgs a;
+    a.boxes = in_boxes;
     a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
     a.D = in_dims[0]; a.H = in_dims[1]; a.W = in_dims[2];
     for (int i = 0; i < 3; ++i) { a.lo[i] = out_need.lo[i] / 2; a.hi[i] = (out_need.hi[i] + 1) / 2; }
@@ -302,8 +307,12 @@ static int launch_pool(const float* in, float* out, const int dims[3], int C, in
 }
 
 // One batch of `n` tiles through the whole network; kept-centre blocks go to blocks_out.
+// `table` (device, may be null) = per-tile boxes [layer][table_tiles][6] of the whole call; this batch starts at tile
+// `t0` of it.  For up-convs the table row holds the INPUT box (the halved output box).
 static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[18], int out_mode,
-                     float* blocks_out, char* ws, const Plan& plan, hipStream_t st) {
+                     float* blocks_out, char* ws, const Plan& plan, hipStream_t st,
+                     const int* table = nullptr, int table_tiles = 0, int t0 = 0) {
+    auto tb = [&](int layer) -> const int* { return table ? table + ((size_t)layer * table_tiles + t0) * 6 : nullptr; };
     const Layer* L = h->L;
     float* buf[B_COUNT];
     for (int i = 0; i < B_COUNT; ++i) buf[i] = reinterpret_cast<float*>(ws + plan.off[i]);
@@ -322,32 +331,35 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     }
     int rc;
 #define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
-    RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st));
+    RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1)));
     RUN(launch_pool(buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
-    RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st));
-    RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st));
+    RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st, tb(EC2)));
+    RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3)));
     RUN(launch_pool(buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
-    RUN(launch_conv3(h, L[EC4], buf[B_P1], nullptr, buf[B_E4], d[2], need[EC4], n, st));
-    RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st));
+    RUN(launch_conv3(h, L[EC4], buf[B_P1], nullptr, buf[B_E4], d[2], need[EC4], n, st, tb(EC4)));
+    RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5)));
     RUN(launch_pool(buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
-    RUN(launch_conv3(h, L[EC6], buf[B_P2], nullptr, buf[B_E6], d[3], need[EC6], n, st));
-    RUN(launch_conv3(h, L[EC7], buf[B_E6], nullptr, buf[B_E7], d[3], need[EC7], n, st));
-    RUN(launch_up(L[DC9], buf[B_E7], buf[B_U9], d[3], need[DC9], n, st));
-    RUN(launch_conv3(h, L[DC8], buf[B_U9], buf[B_SYN2], buf[B_D8], d[2], need[DC8], n, st));   // cat(up, skip) :127
-    RUN(launch_conv3(h, L[DC7], buf[B_D8], nullptr, buf[B_D7], d[2], need[DC7], n, st));
-    RUN(launch_up(L[DC6], buf[B_D7], buf[B_U6], d[2], need[DC6], n, st));
-    RUN(launch_conv3(h, L[DC5], buf[B_U6], buf[B_SYN1], buf[B_D5], d[1], need[DC5], n, st));   // :134
-    RUN(launch_conv3(h, L[DC4], buf[B_D5], nullptr, buf[B_D4], d[1], need[DC4], n, st));
-    RUN(launch_up(L[DC3], buf[B_D4], buf[B_U3], d[1], need[DC3], n, st));
-    RUN(launch_conv3(h, L[DC2], buf[B_U3], buf[B_SYN0], buf[B_D2], d[0], need[DC2], n, st));   // :141
-    RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC1], n, st));
+    RUN(launch_conv3(h, L[EC6], buf[B_P2], nullptr, buf[B_E6], d[3], need[EC6], n, st, tb(EC6)));
+    RUN(launch_conv3(h, L[EC7], buf[B_E6], nullptr, buf[B_E7], d[3], need[EC7], n, st, tb(EC7)));
+    RUN(launch_up(L[DC9], buf[B_E7], buf[B_U9], d[3], need[DC9], n, st, tb(DC9)));
+    RUN(launch_conv3(h, L[DC8], buf[B_U9], buf[B_SYN2], buf[B_D8], d[2], need[DC8], n, st, tb(DC8)));   // cat(up, skip) :127
+    RUN(launch_conv3(h, L[DC7], buf[B_D8], nullptr, buf[B_D7], d[2], need[DC7], n, st, tb(DC7)));
+    RUN(launch_up(L[DC6], buf[B_D7], buf[B_U6], d[2], need[DC6], n, st, tb(DC6)));
+    RUN(launch_conv3(h, L[DC5], buf[B_U6], buf[B_SYN1], buf[B_D5], d[1], need[DC5], n, st, tb(DC5)));   // :134
+    RUN(launch_conv3(h, L[DC4], buf[B_D5], nullptr, buf[B_D4], d[1], need[DC4], n, st, tb(DC4)));
+    RUN(launch_up(L[DC3], buf[B_D4], buf[B_U3], d[1], need[DC3], n, st, tb(DC3)));
+    RUN(launch_conv3(h, L[DC2], buf[B_U3], buf[B_SYN0], buf[B_D2], d[0], need[DC2], n, st, tb(DC2)));   // :141
+    RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC1], n, st, tb(DC1)));
 #undef RUN
-    {   // dc0 + sigmoid/threshold + centre crop
+    {   // dc0 + sigmoid/threshold + centre crop: the launch box is need[DC0]; blocks are laid out over the full kept centre
         const Box& k = need[DC0];
         const int bz = k.hi[0] - k.lo[0], by = k.hi[1] - k.lo[1], bx = k.hi[2] - k.lo[2];
+        const int kz = src.vol ? src.oz : 0, ky = src.vol ? src.oy : 0, kx = src.vol ? src.ox : 0;
+        const int ez = src.vol ? src.ez : src.td, ey = src.vol ? src.ey : src.th, ex = src.vol ? src.ex : src.tw;
         dim3 grid(cdiv((size_t)bz * by * bx, 256), n);
         head_kernel<<<grid, 256, 0, st>>>(buf[B_D1], L[DC0].cin, d[0][0], d[0][1], d[0][2], k.lo[0], k.lo[1], k.lo[2],
-                                          bz, by, bx, L[DC0].plain, L[DC0].shift, h->n_classes, out_mode, blocks_out);
+                                          bz, by, bx, kz, ky, kx, ez, ey, ex, L[DC0].plain, L[DC0].shift, h->n_classes,
+                                          out_mode, blocks_out, tb(DC0));
         OAI_CHECK_LAUNCH();
     }
     return OAI_OK;
@@ -537,46 +549,152 @@ int oai_unet_forward_tiles(oai_unet* h, const float* tiles, float* logits, int B
     return OAI_OK;
 }
 
+// What a tile must produce along one axis: its kept centre [ovl, tile-ovl) clipped to the part of the volume that
+// Partition.assemble keeps (image_transforms.py:504 trims to the image, :509-513 zeroes a frame of `crop` voxels).
+__host__ __device__ static void keep_interval(int t, int eff, int ovl, int size, int crop, int& lo, int& hi) {
+    const int v0 = t * eff;                                   // volume coordinate of the kept centre's first voxel
+    const int a = crop - v0 > 0 ? crop - v0 : 0;
+    const int b = size - crop - v0 < eff ? size - crop - v0 : eff;
+    lo = ovl + a;
+    hi = ovl + b;                                             // hi <= lo: this tile contributes nothing
+}
+
+struct SegGeom {
+    int eff[3], grid[3], ntiles;
+};
+
+static int seg_geometry(int D, int H, int W, const int tile[3], const int overlap[3], SegGeom& g) {
+    const int size[3] = {D, H, W};
+    for (int i = 0; i < 3; ++i) {
+        OAI_CHECK_ARG(overlap[i] >= 0 && tile[i] - 2 * overlap[i] > 0, "overlap too large for the tile");
+        g.eff[i] = tile[i] - 2 * overlap[i];
+        g.grid[i] = (size[i] + g.eff[i] - 1) / g.eff[i];
+    }
+    g.ntiles = g.grid[0] * g.grid[1] * g.grid[2];
+    return OAI_OK;
+}
+
+struct SegParams {          // everything tile_regions needs, by value (kernel argument)
+    int size[3], tile[3], overlap[3], crop[3], eff[3], grid[3];
+    int trimmed;
+};
+
+// need[layer] of tile t (z-major index), or all-empty boxes for a tile that contributes nothing
+__host__ __device__ static void tile_regions(int t, const SegParams& p, Box need[18]) {
+    const int idx[3] = {t / (p.grid[1] * p.grid[2]), (t / p.grid[2]) % p.grid[1], t % p.grid[2]};
+    int lo[3], hi[3];
+    bool dead = false;
+    for (int i = 0; i < 3; ++i) {
+        keep_interval(idx[i], p.eff[i], p.overlap[i], p.size[i], p.crop[i], lo[i], hi[i]);
+        if (hi[i] <= lo[i]) dead = true;
+        if (!p.trimmed) { lo[i] = p.overlap[i]; hi[i] = p.tile[i] - p.overlap[i]; }
+    }
+    plan_regions(p.tile, lo, hi, p.trimmed != 0, need);
+    if (dead && p.trimmed)
+        for (int k = 0; k < 18; ++k) for (int i = 0; i < 3; ++i) need[k].lo[i] = need[k].hi[i] = 0;
+}
+
+// device table [layer][n][6] of tiles [t0, t0+n): computed on the device (no host copy: graph-capturable);
+// up-conv rows hold the INPUT box (the halved output box)
+__global__ void box_table_kernel(SegParams p, int t0, int n, int* __restrict__ table) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Box need[18];
+    tile_regions(t0 + t, p, need);
+    for (int k = 0; k < 18; ++k) {
+        int* row = table + ((size_t)k * n + t) * 6;
+        const bool up = layer_kind(k) == 2;
+        for (int i = 0; i < 3; ++i) {
+            row[i] = up ? need[k].lo[i] / 2 : need[k].lo[i];
+            row[3 + i] = up ? (need[k].hi[i] + 1) / 2 : need[k].hi[i];
+        }
+    }
+}
+
+static SegParams seg_params(int D, int H, int W, const int tile[3], const int overlap[3], const int* crop, const SegGeom& g, bool trimmed) {
+    SegParams p;
+    const int size[3] = {D, H, W};
+    for (int i = 0; i < 3; ++i) {
+        p.size[i] = size[i]; p.tile[i] = tile[i]; p.overlap[i] = overlap[i]; p.crop[i] = crop ? crop[i] : 0;
+        p.eff[i] = g.eff[i]; p.grid[i] = g.grid[i];
+    }
+    p.trimmed = trimmed ? 1 : 0;
+    return p;
+}
+
 int oai_segment_tiles(oai_unet* h, const float* vol, int D, int H, int W, const int tile[3], const int overlap[3],
-                      int tile_begin, int tile_end, int out_mode, float* blocks, int batch,
+                      const int crop[3], int tile_begin, int tile_end, int out_mode, float* blocks, int batch,
                       void* ws, size_t ws_bytes, void* stream) {
     OAI_CHECK_ARG(h && vol && tile && overlap && blocks && ws, "oai_segment_tiles: null pointer");
     OAI_CHECK_ARG(D > 1 && H > 1 && W > 1, "oai_segment_tiles: volume axes must be > 1 (reflect padding)");
     OAI_CHECK_ARG(out_mode >= 0 && out_mode <= 2, "oai_segment_tiles: out_mode must be 0, 1 or 2");
     if (int rc = check_tile(tile[0], tile[1], tile[2])) return rc;
-    int eff[3], grid[3];
-    const int size[3] = {D, H, W};
-    for (int i = 0; i < 3; ++i) {
-        OAI_CHECK_ARG(overlap[i] >= 0 && tile[i] - 2 * overlap[i] > 0, "oai_segment_tiles: overlap too large for the tile");
-        eff[i] = tile[i] - 2 * overlap[i];
-        grid[i] = (size[i] + eff[i] - 1) / eff[i];
-    }
-    const int ntiles = grid[0] * grid[1] * grid[2];
-    OAI_CHECK_ARG(0 <= tile_begin && tile_begin <= tile_end && tile_end <= ntiles,
-                  "oai_segment_tiles: tile range [%d,%d) outside [0,%d)", tile_begin, tile_end, ntiles);
+    SegGeom g;
+    if (int rc = seg_geometry(D, H, W, tile, overlap, g)) return rc;
+    OAI_CHECK_ARG(0 <= tile_begin && tile_begin <= tile_end && tile_end <= g.ntiles,
+                  "oai_segment_tiles: tile range [%d,%d) outside [0,%d)", tile_begin, tile_end, g.ntiles);
     OAI_CHECK_ARG(batch > 0, "oai_segment_tiles: batch must be > 0");
+    if (crop) for (int i = 0; i < 3; ++i) OAI_CHECK_ARG(crop[i] >= 0, "oai_segment_tiles: negative crop");
     const Plan plan = plan_workspace(h, tile[0], tile[1], tile[2], batch);
     if (plan.total > ws_bytes)
         return set_error(OAI_ERR_WORKSPACE, "oai_segment_tiles: workspace %zu B < %zu B needed for batch %d", ws_bytes, plan.total, batch);
-    int lo[3], hi[3];
-    for (int i = 0; i < 3; ++i) { lo[i] = overlap[i]; hi[i] = tile[i] - overlap[i]; }
-    Box need[18];
     const char* notrim = getenv("OAI_NO_TRIM");
-    plan_regions(tile, lo, hi, !(notrim && atoi(notrim)), need);
+    const bool trimmed = !(notrim && atoi(notrim));
+    hipStream_t st = (hipStream_t)stream;
     TileSource src{};
     src.vol = vol; src.tiles = nullptr; src.D = D; src.H = H; src.W = W;
     src.td = tile[0]; src.th = tile[1]; src.tw = tile[2];
-    src.ez = eff[0]; src.ey = eff[1]; src.ex = eff[2];
+    src.ez = g.eff[0]; src.ey = g.eff[1]; src.ex = g.eff[2];
     src.oz = overlap[0]; src.oy = overlap[1]; src.ox = overlap[2];
-    src.gy = grid[1]; src.gx = grid[2];
-    const size_t bvox = (size_t)eff[0] * eff[1] * eff[2];
-    for (int t = tile_begin; t < tile_end; t += batch) {
-        const int n = tile_end - t < batch ? tile_end - t : batch;
-        src.tile_begin = t;
-        if (int rc = run_batch(h, src, n, need, out_mode, blocks + (size_t)(t - tile_begin) * h->n_classes * bvox,
-                               (char*)ws, plan, (hipStream_t)stream)) return rc;
+    src.gy = g.grid[1]; src.gx = g.grid[2];
+    const size_t bvox = (size_t)g.eff[0] * g.eff[1] * g.eff[2];
+    int* table_dev = reinterpret_cast<int*>(ws);
+    const SegParams sp = seg_params(D, H, W, tile, overlap, crop, g, trimmed);
+    Box need[18];
+    for (int c0 = tile_begin; c0 < tile_end; c0 += kMaxTilesPerTable) {
+        const int nc = tile_end - c0 < kMaxTilesPerTable ? tile_end - c0 : kMaxTilesPerTable;
+        box_table_kernel<<<cdiv(nc, 64), 64, 0, st>>>(sp, c0, nc, table_dev);
+        OAI_CHECK_LAUNCH();
+        for (int t = c0; t < c0 + nc; t += batch) {
+            const int n = c0 + nc - t < batch ? c0 + nc - t : batch;
+            // launch boxes of this batch = union over its tiles (host mirror of the same planning code)
+            Box uni[18];
+            for (int k = 0; k < 18; ++k) for (int i = 0; i < 3; ++i) { uni[k].lo[i] = 1 << 30; uni[k].hi[i] = 0; }
+            for (int j = 0; j < n; ++j) {
+                tile_regions(t + j, sp, need);
+                for (int k = 0; k < 18; ++k) {
+                    if (need[k].hi[0] <= need[k].lo[0]) continue;
+                    for (int i = 0; i < 3; ++i) {
+                        if (need[k].lo[i] < uni[k].lo[i]) uni[k].lo[i] = need[k].lo[i];
+                        if (need[k].hi[i] > uni[k].hi[i]) uni[k].hi[i] = need[k].hi[i];
+                    }
+                }
+            }
+            if (uni[0].hi[0] == 0) continue;                 // every tile of the batch is dead
+            src.tile_begin = t;
+            if (int rc = run_batch(h, src, n, uni, out_mode, blocks + (size_t)(t - tile_begin) * h->n_classes * bvox,
+                                   (char*)ws, plan, st, table_dev, nc, t - c0)) return rc;
+        }
     }
     return OAI_OK;
+}
+
+double oai_unet_volume_flops(const oai_unet* h, int D, int H, int W, const int tile[3], const int overlap[3],
+                             const int crop[3], int trimmed, int conv3_only) {
+    if (!h || !tile || !overlap) return 0.0;
+    SegGeom g;
+    if (seg_geometry(D, H, W, tile, overlap, g)) return 0.0;
+    double f = 0.0;
+    Box need[18];
+    const SegParams sp = seg_params(D, H, W, tile, overlap, crop, g, trimmed != 0);
+    for (int t = 0; t < g.ntiles; ++t) {
+        tile_regions(t, sp, need);
+        for (int k = 0; k < 18; ++k) {
+            if (conv3_only && !(k >= 1 && k < 17 && (kKind[k] == 0 || kKind[k] == 1))) continue;
+            f += layer_flops(h, k, need[k]);
+        }
+    }
+    return f;
 }
 
 int oai_stitch_blocks(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],

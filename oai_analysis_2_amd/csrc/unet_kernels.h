@@ -40,7 +40,21 @@ struct ConvArgs {
     int lo[3], hi[3];                        // output box to compute, [lo,hi) in z,y,x
     int nbz, nby, nbx, ncb;                  // spatial blocks, cout blocks of 64
     int relu;
-};
+    const int* boxes;                        // optional [tile][6] (lo z,y,x, hi z,y,x): the part of [lo,hi) THIS tile needs
+};                                           // (tiles at the volume border need less: their kept centre is partly zeroed)
+
+// intersection of the launch box with the tile's own box; false if the block [o, o+t) misses it entirely
+__device__ __forceinline__ bool tile_box(const int* boxes, int tile, const int (&llo)[3], const int (&lhi)[3],
+                                         int (&lo)[3], int (&hi)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lo[i] = llo[i]; hi[i] = lhi[i]; }
+    if (boxes) {
+        const int* b = boxes + 6 * tile;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { lo[i] = max(lo[i], b[i]); hi[i] = min(hi[i], b[3 + i]); }
+    }
+    return lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2];
+}
 
 
 // Tile shape: a 32-row MFMA block is RX x RY voxels (x, y); the 4 waves are arranged WY x WX, so a workgroup covers
@@ -69,7 +83,10 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
     const int bz = id % a.nbz; id /= a.nbz;
     const int tile = id;
     const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * kConvTY, ox0 = a.lo[2] + bx * kConvTX;
-    const int mvalid = min(MREP, a.hi[0] - oz0);   // z slices of this block inside the output box (uniform)
+    int blo[3], bhi[3];                            // what this tile needs of the launch box (wave-uniform)
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + kConvTY <= blo[1] || ox0 >= bhi[2] || ox0 + kConvTX <= blo[2]) return;
+    const int m_lo = max(0, blo[0] - oz0), m_hi = min(MREP, bhi[0] - oz0);   // z slices of this block that are needed
 
     f32x16 acc[MREP][NREP];
 #pragma unroll
@@ -152,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int m = 0; m < MREP; ++m) {
-                    if (m < mvalid) {
+                    if (m >= m_lo && m < m_hi) {
                         const float av = s == 0 ? acur[m].x : s == 1 ? acur[m].y : s == 2 ? acur[m].z : acur[m].w;
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) {
@@ -177,12 +194,12 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
-            if (oz >= a.hi[0]) continue;
+            if (oz < blo[0] || oz >= bhi[0]) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int ox = ox0 + wx * RX + rr % RX, oy = oy0 + wy * RY + rr / RX;
-                if (ox < a.hi[2] && oy < a.hi[1]) {
+                if (ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1]) {
                     float v = acc[m][n][r] * sc + sh;
                     if (a.relu) v = fmaxf(v, 0.0f);
                     a.out[((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co] = v;
@@ -242,7 +259,10 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
     const int bz = id % a.nbz; id /= a.nbz;
     const int tile = id;
     const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * kTY, ox0 = a.lo[2] + bx * kTX;
-    const int mvalid = min(MREP, a.hi[0] - oz0);
+    int blo[3], bhi[3];
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + kTY <= blo[1] || ox0 >= bhi[2] || ox0 + kTX <= blo[2]) return;
+    const int m_lo = max(0, blo[0] - oz0), m_hi = min(MREP, bhi[0] - oz0);
 
     f32x16 acc[MREP][NREP];
 #pragma unroll
@@ -331,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
             for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
                 for (int m = 0; m < MREP; ++m) {
-                    if (m < mvalid) {
+                    if (m >= m_lo && m < m_hi) {
 #pragma unroll
                         for (int n = 0; n < NREP; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
@@ -356,12 +376,12 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
-            if (oz >= a.hi[0]) continue;
+            if (oz < blo[0] || oz >= bhi[0]) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int ox = ox0 + wx * RX + rr % RX, oy = oy0 + wy * RY + rr / RX;
-                if (ox < a.hi[2] && oy < a.hi[1]) {
+                if (ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1]) {
                     float v = acc[m][n][r] * sc + sh;
                     if (a.relu) v = fmaxf(v, 0.0f);
                     a.out[((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co] = v;
@@ -389,6 +409,7 @@ struct UpArgs {
     int nmb;                            // row blocks of 64 voxels per tile
     int nnb;                            // column groups of 256
     int relu;
+    const int* boxes;                   // optional [tile][6]: the part of the INPUT box this tile needs
 };
 
 __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
@@ -403,6 +424,12 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
     const int row = lane & 31, half = lane >> 5;
     const int rz = a.hi[0] - a.lo[0], ry = a.hi[1] - a.lo[1], rx = a.hi[2] - a.lo[2];
     const int nvox = rz * ry * rx;
+    int blo[3], bhi[3];
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    {   // rows are linear over the launch box: skip the block if its z range misses this tile's box
+        const int zf = a.lo[0] + (mb * 64) / (rx * ry), zl = a.lo[0] + min(mb * 64 + 63, nvox - 1) / (rx * ry);
+        if (zl < blo[0] || zf >= bhi[0]) return;
+    }
     const size_t plane = (size_t)a.D * a.H * a.W;
 
     // this lane's A rows (two row blocks of 32 voxels)
@@ -488,8 +515,9 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
                 int x = vx[m][g], y = vy[m][g], z = vz[m][g];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (z < rz) {
-                        const int oz = 2 * (a.lo[0] + z) + pa, oy = 2 * (a.lo[1] + y) + pb, ox = 2 * (a.lo[2] + x) + pc;
+                    const int iz = a.lo[0] + z, iy = a.lo[1] + y, ix = a.lo[2] + x;
+                    if (z < rz && iz >= blo[0] && iz < bhi[0] && iy >= blo[1] && iy < bhi[1] && ix >= blo[2] && ix < bhi[2]) {
+                        const int oz = 2 * iz + pa, oy = 2 * iy + pb, ox = 2 * ix + pc;
                         float val = acc[m][n][4 * g + j] * sc + sh;
                         if (a.relu) val = fmaxf(val, 0.0f);
                         obase[(((size_t)oz * Ho + oy) * Wo + ox) * a.Cout] = val;
@@ -638,14 +666,20 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const float* __restrict__
 // blocks[tile][class][bz][by][bx], one thread per kept voxel.
 __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ in, int Cin, int D, int H, int W,
                                                    int lz, int ly, int lx, int bz, int by, int bx,
+                                                   int kz, int ky, int kx, int ez, int ey, int ex,
                                                    const float* __restrict__ w /*[ncls][Cin]*/, const float* __restrict__ bias,
-                                                   int ncls, int out_mode, float* __restrict__ blocks) {
+                                                   int ncls, int out_mode, float* __restrict__ blocks, const int* __restrict__ boxes) {
+    // launch box [l, l+b) in tile coordinates; the kept-centre block is [k, k+e) and blocks[] is laid out over it
     const size_t nvox = (size_t)bz * by * bx;
     const int tile = blockIdx.y;
     const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= nvox) return;
-    const int x = (int)(v % bx), y = (int)((v / bx) % by), z = (int)(v / ((size_t)bx * by));
-    const float* p = in + (((size_t)tile * D + lz + z) * H + ly + y) * (size_t)W * Cin + (size_t)(lx + x) * Cin;
+    const int x = lx + (int)(v % bx), y = ly + (int)((v / bx) % by), z = lz + (int)(v / ((size_t)bx * by));
+    if (boxes) {            // voxels of the kept centre that stitch zeroes (volume frame) or trims are left unwritten
+        const int* b = boxes + 6 * tile;
+        if (z < b[0] || z >= b[3] || y < b[1] || y >= b[4] || x < b[2] || x >= b[5]) return;
+    }
+    const float* p = in + (((size_t)tile * D + z) * H + y) * (size_t)W * Cin + (size_t)x * Cin;
     float acc[4] = {0, 0, 0, 0};
     for (int c = 0; c < Cin; c += 4) {
         const float4 q = *reinterpret_cast<const float4*>(p + c);
@@ -656,6 +690,8 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ in,
             acc[k] = fmaf(q.w, w[k * Cin + c + 3], acc[k]);
         }
     }
+    const size_t evox = (size_t)ez * ey * ex;
+    const size_t o = ((size_t)(z - kz) * ey + (y - ky)) * ex + (x - kx);
     for (int k = 0; k < ncls; ++k) {
         float l = acc[k] + bias[k];
         float r = l;
@@ -663,7 +699,7 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ in,
             const float pr = 1.0f / (1.0f + expf(-l));          // fp32 sigmoid, IEEE divide
             r = out_mode == 1 ? (pr > 0.5f ? 1.0f : 0.0f) : pr;  // literally sigmoid(x) > 0.5 (SURVEY D-4)
         }
-        blocks[((size_t)tile * ncls + k) * nvox + v] = r;
+        blocks[((size_t)tile * ncls + k) * evox + o] = r;
     }
 }
 

@@ -43,7 +43,7 @@ class VolumePipeline:
         self._atlas_net = None
 
     def segment(self, vol: torch.Tensor, out_mode: int = 0, tile_range: Optional[Tuple[int, int]] = None):
-        blocks = self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, tile_range, out_mode, self.batch)
+        blocks = self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, tile_range, out_mode, self.batch, self.crop_zyx)
         if tile_range is not None:
             return blocks
         return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
@@ -66,7 +66,7 @@ class VolumePipeline:
         from . import parallel
         _, _, n_tiles = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
         blocks = parallel.segment_tile_sharded(
-            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch), n_tiles, group)
+            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx), n_tiles, group)
         return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
 
     def run_sharded(self, vol: torch.Tensor, meta_A: Image, group=None) -> VolumeResult:

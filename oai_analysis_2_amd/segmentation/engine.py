@@ -139,9 +139,16 @@ class UNetEngine:
                        "oai_unet_forward_tiles")
         return out
 
+    def volume_flops(self, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None, trimmed: bool = True, conv3_only: bool = False) -> float:
+        return float(self.lib.oai_unet_volume_flops(self._h, *[int(v) for v in size_zyx], _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
+                                                    _lib.int3(crop_zyx) if crop_zyx is not None else None, int(trimmed), int(conv3_only)))
+
     def segment_tiles(self, vol: torch.Tensor, tile_zyx, overlap_zyx, tile_range: Optional[Tuple[int, int]] = None,
-                      out_mode: int = 0, batch: int = 32) -> torch.Tensor:
-        """Kept-centre blocks [n_local, n_classes, ez, ey, ex] of tiles [begin,end) of the volume."""
+                      out_mode: int = 0, batch: int = 32, crop_zyx=None) -> torch.Tensor:
+        """Kept-centre blocks [n_local, n_classes, ez, ey, ex] of tiles [begin,end) of the volume.
+
+        ``crop_zyx``: the frame ``stitch`` will zero; block voxels inside it (and beyond the image) are not computed
+        and hold unspecified values."""
         vol = vol.to(self.device, torch.float32).contiguous()
         D, H, W = vol.shape
         eff, grid, ntiles = tile_grid((D, H, W), tile_zyx, overlap_zyx)
@@ -152,6 +159,7 @@ class UNetEngine:
         if end > begin:
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.oai_segment_tiles(self._h, vol.data_ptr(), D, H, W, _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
+                                                      _lib.int3(crop_zyx) if crop_zyx is not None else None,
                                                       int(begin), int(end), int(out_mode), blocks.data_ptr(), batch,
                                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                            "oai_segment_tiles")

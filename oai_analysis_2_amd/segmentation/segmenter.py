@@ -87,7 +87,8 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         # batch_size of the reference config is a host-loop knob (4 tiles per H2D/D2H round trip, segmenter.py:109-119);
         # here it only sizes the activation workspace, so use a device-sized batch unless told otherwise
         batch = int(self.config.get("device_batch_size", 32))
-        blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch)
+        blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
+                                   crop_zyx if min(crop_zyx) > 0 else None)
         if tile_range is not None:
             return blocks
         if min(crop_zyx) == 0:

@@ -12,7 +12,7 @@ vol = torch.from_numpy(make_volume(0)).cuda()
 tile, ovl = (32, 128, 128), (8, 16, 16)
 for rep in range(2):
     torch.cuda.synchronize(); t = time.time()
-    b = eng.segment_tiles(vol, tile, ovl, (0, ntiles), 0, batch)
+    b = eng.segment_tiles(vol, tile, ovl, (0, ntiles), 0, batch, (8, 16, 16) if int(os.environ.get('CROP', '1')) else None)
     torch.cuda.synchronize(); dt = time.time() - t
     fl_t = eng.tile_flops(tile, ovl, True) * ntiles; fl_f = eng.tile_flops(tile, ovl, False) * ntiles
     notrim = bool(int(os.environ.get("OAI_NO_TRIM", "0")))

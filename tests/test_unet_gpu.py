@@ -75,6 +75,8 @@ def test_segment_small_matches_reference_golden(golden_dir, precision):
     crop_zyx = (ovl[2], ovl[0], ovl[1])             # assemble indexes crop_size as (x,y,z): image_transforms.py:511-512
     blocks = eng.segment_tiles(v, tile_zyx, ovl_zyx, out_mode=0, batch=7)    # ragged last batch
     maps = eng.stitch(blocks, vol.shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy().astype(np.float64)
+    trimmed = eng.stitch(eng.segment_tiles(v, tile_zyx, ovl_zyx, out_mode=0, batch=7, crop_zyx=crop_zyx), vol.shape, tile_zyx, ovl_zyx, crop_zyx)
+    assert np.array_equal(trimmed.cpu().numpy().astype(np.float64), maps)   # border-tile trimming is bit-identical
     # the reference's own acceptance test: sum|d| < 12 per 23.6M voxels (test/test_all.py:32-33)
     budget = 12.0 * vol.size / 23592960
     assert np.abs(maps[0] - z["fc_prob"]).sum() < budget
@@ -88,8 +90,9 @@ def test_segment_small_matches_reference_golden(golden_dir, precision):
         assert diff.sum() <= 3, f"{diff.sum()} mask voxels differ"
         assert np.all(np.abs(prob[diff] - 0.5) < 1e-5)
     # tile-range sharding (the multi-GPU path) produces the same blocks
-    part = torch.cat([eng.segment_tiles(v, tile_zyx, ovl_zyx, (0, 30), 0, 8), eng.segment_tiles(v, tile_zyx, ovl_zyx, (30, 75), 0, 8)])
-    assert torch.equal(part, blocks)
+    # (block voxels beyond the image / inside the zeroed frame are unspecified, so compare what stitch makes of them)
+    part = torch.cat([eng.segment_tiles(v, tile_zyx, ovl_zyx, (0, 30), 0, 8, crop_zyx), eng.segment_tiles(v, tile_zyx, ovl_zyx, (30, 75), 0, 8, crop_zyx)])
+    assert np.array_equal(eng.stitch(part, vol.shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy().astype(np.float64), maps)
 
 
 def test_cohort_runner_matches_single_runs():
@@ -143,6 +146,11 @@ def test_segment_ragged_volumes_vs_oracle(shape, patch, ovl):
     blocks = eng.segment_tiles(torch.from_numpy(vol).cuda(), tile_zyx, ovl_zyx, out_mode=0, batch=5)
     maps = eng.stitch(blocks, shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
     assert np.abs(maps[0] - fc_ref).max() < 1e-5 and np.abs(maps[1] - tc_ref).max() < 1e-5
+    # border-tile trimming (the frame stitch zeroes is not computed) must not change a single stitched voxel
+    blocks2 = eng.segment_tiles(torch.from_numpy(vol).cuda(), tile_zyx, ovl_zyx, out_mode=0, batch=5, crop_zyx=crop_zyx)
+    maps2 = eng.stitch(blocks2, shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
+    assert np.array_equal(maps2, maps)
+    assert eng.volume_flops(shape, tile_zyx, ovl_zyx, crop_zyx) < eng.volume_flops(shape, tile_zyx, ovl_zyx, None)
     assert maps[0][:crop_zyx[0]].max() == 0 and maps[0][:, :, -crop_zyx[2]:].max() == 0      # the zeroed frame
 
 
