@@ -5,9 +5,7 @@
 // Reference semantics restated (see include/oai_hip.h for the call sites):
 //   torch.nn.functional.grid_sample(mode='bilinear', padding_mode='border', align_corners=True)
 //   behind icon_registration.mermaidlite.compute_warped_image_multiNC (scale_map: g = 2*c - 1,
-//   channel reversal to xyz).  One thread owns VEC consecutive x voxels: coordinate planes are
-//   read and results written with 16-byte accesses; the 8-tap gathers hit neighbouring lines
-//   because registration maps are near-identity.
+//   channel reversal to xyz).  One lane per output voxel, the 8 corners fetched as 4 x-adjacent pairs.
 #include "common.h"
 
 namespace {
@@ -26,92 +24,97 @@ __device__ __forceinline__ float unnormalize_border(float c01, int size) {
     return fminf((float)(size - 1), fmaxf(ix, 0.0f));
 }
 
+// The 8 corners as 4 x-adjacent PAIRS: one 8-byte load fetches (x0, x0+1).  x0 is clamped to w-2 so that the pair
+// exists; at the upper border (ix == w-1 exactly) all weight moves to the second element, which is what PyTorch's
+// skipped out-of-range corner (weight 0) amounts to.  Same for y and z through clamped row/plane indices.
 struct Taps {
-    int o[8];      // linear offsets of the 8 corners inside one [d][h][w] plane, or -1
-    float w[8];
+    int o[4];      // offsets of the pairs (z0,y0) (z0,y1) (z1,y0) (z1,y1) inside one [d][h][w] plane
+    float wx0, wx1, wy0, wy1, wz0, wz1;
 };
 
 __device__ __forceinline__ void make_taps(float cz, float cy, float cx, int d, int h, int w, Taps& t) {
     const float iz = unnormalize_border(cz, d), iy = unnormalize_border(cy, h), ix = unnormalize_border(cx, w);
     const float fz0 = floorf(iz), fy0 = floorf(iy), fx0 = floorf(ix);
-    const int z0 = (int)fz0, y0 = (int)fy0, x0 = (int)fx0;
-    const float wz1 = iz - fz0, wy1 = iy - fy0, wx1 = ix - fx0;          // weight of the "+1" corner
-    const float wz0 = (fz0 + 1.0f) - iz, wy0 = (fy0 + 1.0f) - iy, wx0 = (fx0 + 1.0f) - ix;
-    const bool zin = z0 + 1 < d, yin = y0 + 1 < h, xin = x0 + 1 < w;     // the "+1" corner exists
-    const int base = (z0 * h + y0) * w + x0;
-    // PyTorch order: tnw tne tsw tse bnw bne bsw bse  (t/b = z, n/s = y, w/e = x)
-    t.o[0] = base;                         t.w[0] = wx0 * wy0 * wz0;
-    t.o[1] = xin ? base + 1 : -1;          t.w[1] = wx1 * wy0 * wz0;
-    t.o[2] = yin ? base + w : -1;          t.w[2] = wx0 * wy1 * wz0;
-    t.o[3] = (xin && yin) ? base + w + 1 : -1;   t.w[3] = wx1 * wy1 * wz0;
-    const int bz = base + h * w;
-    t.o[4] = zin ? bz : -1;                t.w[4] = wx0 * wy0 * wz1;
-    t.o[5] = (zin && xin) ? bz + 1 : -1;   t.w[5] = wx1 * wy0 * wz1;
-    t.o[6] = (zin && yin) ? bz + w : -1;   t.w[6] = wx0 * wy1 * wz1;
-    t.o[7] = (zin && xin && yin) ? bz + w + 1 : -1;   t.w[7] = wx1 * wy1 * wz1;
+    const int z0 = (int)fz0, y0 = (int)fy0;
+    int x0 = (int)fx0;
+    float wx1 = ix - fx0, wx0 = (fx0 + 1.0f) - ix;      // PyTorch's weights: (ix - floor), (floor + 1 - ix)
+    if (x0 > w - 2) { x0 = w - 2; wx0 = 0.0f; wx1 = 1.0f; }   // ix == w-1: the in-range corner carries weight 1
+    t.wx0 = wx0; t.wx1 = wx1;
+    t.wy1 = iy - fy0; t.wy0 = (fy0 + 1.0f) - iy;
+    t.wz1 = iz - fz0; t.wz0 = (fz0 + 1.0f) - iz;
+    const int z1 = min(z0 + 1, d - 1), y1 = min(y0 + 1, h - 1);   // clamped twin carries weight 0 at the border
+    t.o[0] = (z0 * h + y0) * w + x0;
+    t.o[1] = (z0 * h + y1) * w + x0;
+    t.o[2] = (z1 * h + y0) * w + x0;
+    t.o[3] = (z1 * h + y1) * w + x0;
 }
 
+struct __attribute__((packed, aligned(4))) pair_f32 { float a, b; };      // 8-byte load at 4-byte alignment (dwordx2)
+
+// (Tried and rejected: fetching only x0 and taking x0+1 from the neighbour lane by ds_bpermute -- the cross-lane moves
+// and the masked fix-up load cost more than the second dword: 36 us instead of 23 us for the 160^3 warp.)
 __device__ __forceinline__ float gather8(const float* __restrict__ plane, const Taps& t) {
+    const pair_f32 p00 = *reinterpret_cast<const pair_f32*>(plane + t.o[0]);
+    const pair_f32 p01 = *reinterpret_cast<const pair_f32*>(plane + t.o[1]);
+    const pair_f32 p10 = *reinterpret_cast<const pair_f32*>(plane + t.o[2]);
+    const pair_f32 p11 = *reinterpret_cast<const pair_f32*>(plane + t.o[3]);
+    // PyTorch order and weight products: tnw tne tsw tse bnw bne bsw bse, weight = wx * wy * wz
     float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (t.o[k] >= 0) acc += plane[t.o[k]] * t.w[k];
+    acc += p00.a * (t.wx0 * t.wy0 * t.wz0);
+    acc += p00.b * (t.wx1 * t.wy0 * t.wz0);
+    acc += p01.a * (t.wx0 * t.wy1 * t.wz0);
+    acc += p01.b * (t.wx1 * t.wy1 * t.wz0);
+    acc += p10.a * (t.wx0 * t.wy0 * t.wz1);
+    acc += p10.b * (t.wx1 * t.wy0 * t.wz1);
+    acc += p11.a * (t.wx0 * t.wy1 * t.wz1);
+    acc += p11.b * (t.wx1 * t.wy1 * t.wz1);
     return acc;
 }
 
 // MODE 0: out[c] = sample(src[c], coords)            (image / field warp, C channels)
 // MODE 1: out[c] = coords[c] + sample(src[c], coords) (compose, C == 3)
 // coords == nullptr -> identity map of the output grid.
-template <int MODE, int VEC>
+// One lane = one output voxel, consecutive lanes = consecutive x: for near-identity maps a wave's 64 pair loads fall in
+// two or three 128-byte lines (a lane-per-4-voxels layout touches 8 lines per load and is 3x slower).
+// One lane = one output voxel.  A block is a 32(x) x 4(y) x 2(z) brick: lanes of a wave are 32 consecutive x on two
+// rows (coalesced 128-byte coordinate reads / result writes, pair loads falling in two or three lines), and the four
+// waves' source rows overlap, so the 2x2 (y,z) re-use of every source row is served by the CU's L1 instead of L2.
+template <int MODE, typename IDX>
 __global__ void __launch_bounds__(kThreads)
 sample_kernel(const float* __restrict__ src, int C, int d, int h, int w,
               const float* __restrict__ coords, int D, int H, int W, float* __restrict__ out) {
-    const long long plane_out = (long long)D * H * W;
-    const long long plane_src = (long long)d * h * w;
-    const long long nvec = plane_out / VEC;
+    const IDX plane_out = (IDX)D * H * W;
+    const IDX plane_src = (IDX)d * h * w;
     const double inz = 1.0 / (D - 1), iny = 1.0 / (H - 1), inx = 1.0 / (W - 1);
-    for (long long v = (long long)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (long long)gridDim.x * kThreads) {
-        const long long lin = v * VEC;
-        const int x = (int)(lin % W);
-        const int y = (int)((lin / W) % H);
-        const int z = (int)(lin / ((long long)W * H));
-        float cz[VEC], cy[VEC], cx[VEC];
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) & 3, tz = threadIdx.x >> 7;
+    constexpr int U = 2;       // two bricks per block (z and z + half the z-bricks): their coordinate loads, then their
+                               // gathers, are in flight together.  3-D grid: no index divisions, 32-bit offsets (IDX).
+    const int x = blockIdx.x * 32 + tx, y = blockIdx.y * 4 + ty;
+    IDX lin[U];
+    bool ok[U];
+    float cz[U], cy[U], cx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int z = (blockIdx.z + u * gridDim.z) * 2 + tz;
+        ok[u] = x < W && y < H && z < D;
+        lin[u] = ok[u] ? ((IDX)z * H + y) * W + x : 0;
         if (coords) {
-            if constexpr (VEC == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(coords + lin);
-                const float4 b = *reinterpret_cast<const float4*>(coords + plane_out + lin);
-                const float4 c = *reinterpret_cast<const float4*>(coords + 2 * plane_out + lin);
-                cz[0] = a.x; cz[1] = a.y; cz[2] = a.z; cz[3] = a.w;
-                cy[0] = b.x; cy[1] = b.y; cy[2] = b.z; cy[3] = b.w;
-                cx[0] = c.x; cx[1] = c.y; cx[2] = c.z; cx[3] = c.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    cz[i] = coords[lin + i]; cy[i] = coords[plane_out + lin + i]; cx[i] = coords[2 * plane_out + lin + i];
-                }
-            }
+            cz[u] = coords[lin[u]]; cy[u] = coords[plane_out + lin[u]]; cx[u] = coords[2 * plane_out + lin[u]];
         } else {
-            const float fz = identity_coord(z, inz), fy = identity_coord(y, iny);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) { cz[i] = fz; cy[i] = fy; cx[i] = identity_coord(x + i, inx); }
+            cz[u] = identity_coord(z, inz); cy[u] = identity_coord(y, iny); cx[u] = identity_coord(x, inx);
         }
-        Taps t[VEC];
+    }
+    Taps t[U];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) make_taps(cz[i], cy[i], cx[i], d, h, w, t[i]);
-        for (int c = 0; c < C; ++c) {
-            const float* plane = src + c * plane_src;
-            float r[VEC];
+    for (int u = 0; u < U; ++u) make_taps(cz[u], cy[u], cx[u], d, h, w, t[u]);
+    for (int c = 0; c < C; ++c) {
+        float r[U];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                r[i] = gather8(plane, t[i]);
-                if constexpr (MODE == 1) r[i] += (c == 0 ? cz[i] : (c == 1 ? cy[i] : cx[i]));
-            }
-            float* o = out + c * plane_out + lin;
-            if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
-            else {
+        for (int u = 0; u < U; ++u) r[u] = gather8(src + c * plane_src, t[u]);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) o[i] = r[i];
-            }
+        for (int u = 0; u < U; ++u) {
+            if constexpr (MODE == 1) r[u] += (c == 0 ? cz[u] : (c == 1 ? cy[u] : cx[u]));
+            if (ok[u]) out[c * plane_out + lin[u]] = r[u];
         }
     }
 }
@@ -277,13 +280,12 @@ inline unsigned grid_for(long long work_items) {
 template <int MODE>
 int launch_sample(const float* src, int C, int d, int h, int w, const float* coords, int D, int H, int W,
                   float* out, hipStream_t s) {
-    const long long plane = (long long)D * H * W;
-    const bool vec4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
-                      (coords == nullptr || (reinterpret_cast<uintptr_t>(coords) & 15) == 0);
-    if (vec4)
-        sample_kernel<MODE, 4><<<grid_for(plane / 4), kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
-    else
-        sample_kernel<MODE, 1><<<grid_for(plane), kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
+    const int nbx = (W + 31) / 32, nby = (H + 3) / 4, nbz = (D + 1) / 2;
+    if (nby > 65535 || (nbz + 1) / 2 > 65535) return oai::set_error(OAI_ERR_ARG, "volume too large for the sample grid");
+    dim3 grid(nbx, nby, (nbz + 1) / 2);
+    const long long big = (long long)C * D * H * W > (long long)C * d * h * w ? (long long)C * D * H * W : (long long)C * d * h * w;
+    if (big < (1LL << 31)) sample_kernel<MODE, int><<<grid, kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
+    else sample_kernel<MODE, long long><<<grid, kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
