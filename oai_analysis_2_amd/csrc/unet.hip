@@ -243,9 +243,11 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
 // One conv layer = the main launch over the part of the output box that 8 x 16 (y, x) tiles cover exactly, plus up
 // to two thin remainder strips computed with tile shapes that fit them (trimmed boxes are e.g. 18 x 98 x 98).
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
-                        const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr) {
+                        const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
+                        float* pool_out = nullptr) {
     ConvArgs a;
     a.boxes = boxes;
+    a.pool_out = pool_out;
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
     a.out = out; a.Cout = L.cout; a.scale = L.scale; a.shift = L.shift;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : 1];
@@ -297,6 +299,13 @@ static int launch_up(const Layer& L, const float* src, float* out, const int in_
     return OAI_OK;
 }
 
+// MaxPool3d(2) can ride in the conv epilogue when the (full) box is tiled exactly by the main 4 x 8 x 16 shape
+static bool pool_fusable(const oai_unet* h, const int dims[3], const Box& box) {
+    if (h->variant != 0) return false;
+    for (int i = 0; i < 3; ++i) if (box.lo[i] != 0 || box.hi[i] != dims[i]) return false;
+    return dims[0] % 4 == 0 && dims[1] % 8 == 0 && dims[2] % 16 == 0;
+}
+
 static int launch_pool(const float* in, float* out, const int dims[3], int C, int ntiles, hipStream_t st) {
     const size_t total4 = (size_t)ntiles * (dims[0] / 2) * (dims[1] / 2) * (dims[2] / 2) * (C / 4);
     size_t blocks = (total4 + 255) / 256;
@@ -331,14 +340,26 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     }
     int rc;
 #define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
-    RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1)));
-    RUN(launch_pool(buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
+    if (pool_fusable(h, d[0], need[EC1])) {
+        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0]));
+    } else {
+        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1)));
+        RUN(launch_pool(buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
+    }
     RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st, tb(EC2)));
-    RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3)));
-    RUN(launch_pool(buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
+    if (pool_fusable(h, d[1], need[EC3])) {
+        RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3), buf[B_P1]));
+    } else {
+        RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3)));
+        RUN(launch_pool(buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
+    }
     RUN(launch_conv3(h, L[EC4], buf[B_P1], nullptr, buf[B_E4], d[2], need[EC4], n, st, tb(EC4)));
-    RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5)));
-    RUN(launch_pool(buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
+    if (pool_fusable(h, d[2], need[EC5])) {
+        RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5), buf[B_P2]));
+    } else {
+        RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5)));
+        RUN(launch_pool(buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
+    }
     RUN(launch_conv3(h, L[EC6], buf[B_P2], nullptr, buf[B_E6], d[3], need[EC6], n, st, tb(EC6)));
     RUN(launch_conv3(h, L[EC7], buf[B_E6], nullptr, buf[B_E7], d[3], need[EC7], n, st, tb(EC7)));
     RUN(launch_up(L[DC9], buf[B_E7], buf[B_U9], d[3], need[DC9], n, st, tb(DC9)));

@@ -41,7 +41,9 @@ struct ConvArgs {
     int nbz, nby, nbx, ncb;                  // spatial blocks, cout blocks of 64
     int relu;
     const int* boxes;                        // optional [tile][6] (lo z,y,x, hi z,y,x): the part of [lo,hi) THIS tile needs
-};                                           // (tiles at the volume border need less: their kept centre is partly zeroed)
+                                             // (tiles at the volume border need less: their kept centre is partly zeroed)
+    float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
+};
 
 // intersection of the launch box with the tile's own box; false if the block [o, o+t) misses it entirely
 __device__ __forceinline__ bool tile_box(const int* boxes, int tile, const int (&llo)[3], const int (&lhi)[3],
@@ -56,6 +58,27 @@ __device__ __forceinline__ bool tile_box(const int* boxes, int tile, const int (
     return lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2];
 }
 
+
+// MaxPool3d(2) fused into the conv epilogue (networks.py:112,117,122: pool(relu(conv))).  With the main tile shape a
+// lane's 16 accumulator rows are x in {0..3, 8..11} (+4 for the upper half-wave) on 2 y rows, and its MREP accumulators
+// are consecutive z slices, so every 2x2x2 pooling window lies in one lane's registers: no cross-lane traffic.
+// Requires even block origins and an even number of z slices (host checks); v = epilogue(acc) is applied before the max.
+template <int MREP, typename F>
+__device__ __forceinline__ void pooled_store(const ConvArgs& a, int tile, int co, int oz0, int oy, int ox0, int half, F&& value) {
+    const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
+#pragma unroll
+    for (int m = 0; m < MREP; m += 2)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)              // x group: rows 0..3 / 8..11 (+4*half)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {        // x pair inside the group
+                const int r0 = 4 * g + 2 * p;    // registers r0, r0+1 (y row 0) and r0+8, r0+9 (y row 1)
+                float v = fmaxf(fmaxf(value(m, r0), value(m, r0 + 1)), fmaxf(value(m, r0 + 8), value(m, r0 + 9)));
+                v = fmaxf(v, fmaxf(fmaxf(value(m + 1, r0), value(m + 1, r0 + 1)), fmaxf(value(m + 1, r0 + 8), value(m + 1, r0 + 9))));
+                const int x = ox0 + 8 * g + 4 * half + 2 * p;
+                a.pool_out[((((size_t)tile * Dp + (oz0 + m) / 2) * Hp + oy / 2) * Wp + x / 2) * a.Cout + co] = v;
+            }
+}
 
 // Tile shape: a 32-row MFMA block is RX x RY voxels (x, y); the 4 waves are arranged WY x WX, so a workgroup covers
 // MREP x (WY*RY) x (WX*RX) voxels.  The main shape is <16,2,4,1> (4 x 8 x 16); the other shapes exist for the thin
@@ -204,6 +227,15 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
                     if (a.relu) v = fmaxf(v, 0.0f);
                     a.out[((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co] = v;
                 }
+            }
+        }
+        if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1 && MREP % 2 == 0) {
+            if (a.pool_out) {
+                const bool relu = a.relu != 0;
+                pooled_store<MREP>(a, tile, co, oz0, oy0 + 2 * wy, ox0, half, [&](int m, int r) {
+                    const float v = acc[m][n][r] * sc + sh;
+                    return relu ? fmaxf(v, 0.0f) : v;
+                });
             }
         }
     }
@@ -386,6 +418,15 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
                     if (a.relu) v = fmaxf(v, 0.0f);
                     a.out[((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co] = v;
                 }
+            }
+        }
+        if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1 && MREP % 2 == 0) {
+            if (a.pool_out) {
+                const bool relu = a.relu != 0;
+                pooled_store<MREP>(a, tile, co, oz0, oy0 + 2 * wy, ox0, half, [&](int m, int r) {
+                    const float v = acc[m][n][r] * sc + sh;
+                    return relu ? fmaxf(v, 0.0f) : v;
+                });
             }
         }
     }
