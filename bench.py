@@ -81,9 +81,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ          # launched by torch.distributed.run (also with one rank)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
     from oai_analysis_2_amd import _lib
     from oai_analysis_2_amd.image import Image
@@ -115,20 +117,20 @@ def main():
     torch.cuda.synchronize()
     unet.profile_read()
     unet.profile(True)                                                    # HIP events around the dominant kernel
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         res = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     conv_ms, conv_launches = unet.profile_read()
     unet.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -198,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vols_np[0], meta, atlas, unet_sd, icon_sd)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

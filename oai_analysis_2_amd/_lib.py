@@ -6,7 +6,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboai_hip.so")
+LIB_PATH = os.environ.get("OAI_LIB_PATH") or os.path.join(HERE, "liboai_hip.so")   # override: diagnostic builds only
 
 
 class OaiError(RuntimeError):

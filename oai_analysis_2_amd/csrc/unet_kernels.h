@@ -10,6 +10,13 @@
 
 namespace oai {
 
+// Diagnostic builds only (never shipped: results are wrong): -DOAI_ABLATE=<bits> removes one ingredient of the conv
+// kernels so that its share of the time can be read off (cdna_hip_programming.md 5.4: ablate before optimising).
+//   1 = no halo staging (global loads + LDS writes), 2 = no weight loads, 4 = no LDS fragment reads
+#ifndef OAI_ABLATE
+#define OAI_ABLATE 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
@@ -170,9 +177,9 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                     // every wave is done reading the previous chunk
-        halo_store();
+        if (!(OAI_ABLATE & 1)) halo_store();
         __syncthreads();
-        if (ch + 1 < nchunks) halo_load(ch + 1);             // in flight behind this chunk's 27*KG*MREP*8 MFMAs
+        if (!(OAI_ABLATE & 1) && ch + 1 < nchunks) halo_load(ch + 1);   // in flight behind this chunk's 27*KG*MREP*8 MFMAs
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             const int t = st / KG, kg = st % KG;
@@ -182,10 +189,10 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
             float4 acur[MREP];
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
-                acur[m] = *reinterpret_cast<const float4*>(
+                acur[m] = (OAI_ABLATE & 4) ? bcur[0] : *reinterpret_cast<const float4*>(
                     a_ptr + (((m + dz) * kConvHY + dy) * kConvHX + dx) * STRIDE + 8 * kg);
 #pragma unroll
-            for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
+            for (int n = 0; n < NREP; ++n) bnext[n] = (OAI_ABLATE & 2) ? bcur[n] : wp[n * 64];
             wp += NREP * 64;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -361,9 +368,9 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
-        halo_store();
+        if (!(OAI_ABLATE & 1)) halo_store();
         __syncthreads();
-        if (ch + 1 < nchunks) halo_load(ch + 1);
+        if (!(OAI_ABLATE & 1) && ch + 1 < nchunks) halo_load(ch + 1);
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
             const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
@@ -372,11 +379,11 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
             for (int k = 0; k < NS; ++k)
 #pragma unroll
                 for (int m = 0; m < MREP; ++m)
-                    acur[k][m] = *reinterpret_cast<const float4*>(a_ptr + (((m + dz) * HY + dy) * HX + dx) * REC + k * 32);
+                    acur[k][m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(a_ptr + (((m + dz) * HY + dy) * HX + dx) * REC + k * 32);
 #pragma unroll
             for (int k = 0; k < NS; ++k)
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
+                for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
             wp += STEP;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

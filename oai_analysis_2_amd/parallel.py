@@ -39,7 +39,7 @@ def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None) -> torch
     Uneven ranges (n_tiles % world != 0) are padded to the largest range for the collective.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local_blocks
     rank = dist.get_rank(group)
     counts = [tile_range_for_rank(n_tiles, r, world) for r in range(world)]
