@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 VOL_SHAPE = (160, 384, 384)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
-PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3}
+PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}
+SUSTAINED_16BIT_MFMA_TFLOPS = 1857.0   # scripts/micro/mfma_peak.hip on this chip: operands in registers, every CU (profiles/r01_ablation.md)
 
 
 def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
@@ -64,8 +65,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="tiles per U-Net pass (sizes the activation workspace)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"],
-                    help="arithmetic of the 3x3x3 conv layers: exact fp32 MFMA, or split-bf16 with 6 / 3 MFMA passes")
+    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "f32", "bf16x6", "bf16x3"],
+                    help="arithmetic of the 3x3x3 conv layers.  fp16x3 (default): every fp32 operand split into two fp16 terms, "
+                         "3 MFMA passes, fp32 accumulate -- fp32-grade results (same parity margins as f32 in tests/); "
+                         "f32: exact fp32 MFMA; bf16x6 / bf16x3: split-bf16 with 6 / 3 passes")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "tileshard"],
                     help="N>1: replicas = one volume per rank per step (weak scaling, no collective); tileshard = every step "
                          "is ONE volume whose 160 tiles are split over the ranks + one RCCL all_gather (strong scaling)")
@@ -130,6 +133,7 @@ def main():
     dt = time.perf_counter() - t0
     conv_ms, conv_launches = unet.profile_read()
     unet.profile(False)
+    overflow = unet.range_overflow() if args.precision == "fp16x3" else False
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,27 +164,34 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
-                      "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)"}[args.precision], "data": "synthetic",
+                      "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
+                      "fp16x3": "fp16x3 (fp32 operands split into 2 fp16 terms = 22 mantissa bits, 3 MFMA passes, fp32 accumulate; "
+                                "fp32 activations in memory)"}[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": args.batch, "parallelism": f"{args.mode} x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if args.precision == "f32" else "conv3_igemm_bf16s",
+            "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if args.precision == "f32" else "conv3_igemm_bf16s (split 16-bit)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic if args.precision == "f32" else None,
+                         "traffic": traffic if args.precision == "f32" else None,   # PMC passes were run on the fp32 kernels only
                          "achieved_frame_aware": achieved_fa, "frac_frame_aware": achieved_fa / peak,
                          "mfma_passes_per_product": PASSES[args.precision],
                          "executed_frac": achieved_fa * PASSES[args.precision] / peak,
+                         "executed_frac_of_sustained_issue_rate": None if args.precision == "f32" else
+                         achieved_fa * PASSES[args.precision] / SUSTAINED_16BIT_MFMA_TFLOPS,
                          "algorithmic_flops_per_launch": alg_conv3 / max(conv_launches, 1),
                          "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
+            "fp16_range_overflow": overflow,
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
             "segment_frame_aware_tflop_per_volume": unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, False) / 1e12,
         }
-        if world == 1 and args.precision == "f32" and not args.no_alt:
-            # the same workload with the fp32-grade split-bf16 conv kernels (6 MFMA passes per product); reported beside
-            # the primary fp32 number, never as `value`
-            unet.set_precision("bf16x6")
+        if world == 1 and not args.no_alt:
+            # the same workload with the other arithmetic (exact fp32 MFMA when the primary is split-fp16, and vice versa);
+            # reported beside the primary number, never as `value`
+            alt = "f32" if args.precision != "f32" else "fp16x3"
+            unet.set_precision(alt)
             step(0)
             torch.cuda.synchronize()
+            unet.profile_read()
             unet.profile(True)
             ta = time.perf_counter()
             n_alt = min(2, args.steps)
@@ -190,13 +201,17 @@ def main():
             dta = time.perf_counter() - ta
             ms_a, n_a = unet.profile_read()
             unet.profile(False)
-            unet.set_precision("f32")
+            unet.set_precision(args.precision)
             ach = survey_conv3 * n_alt / (ms_a * 1e-3) / 1e12
-            out["alt_precision"] = {"precision": "bf16x6", "value": n_alt / dta, "unit": "volumes/s", "ms_per_step": 1e3 * dta / n_alt,
-                                    "roofline": {"bound": "mfma", "kernel": "conv3_igemm_bf16s", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                                 "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "mfma_passes_per_product": 6,
-                                                 "executed_frac": 6 * ach * vol_conv3 / survey_conv3 / MFMA_BF16_PEAK_TFLOPS},
-                                    "parity": "same gates as f32 (tests/test_unet_gpu.py: logits <= 1e-4 rel, sum|dp| < 12 per 23.6M voxels)"}
+            pk = MFMA_F32_PEAK_TFLOPS if alt == "f32" else MFMA_BF16_PEAK_TFLOPS
+            out["alt_precision"] = {"precision": alt, "value": n_alt / dta, "unit": "volumes/s", "ms_per_step": 1e3 * dta / n_alt,
+                                    "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if alt == "f32" else "conv3_igemm_bf16s (split 16-bit)",
+                                                 "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
+                                                 "achieved_frame_aware": ach * vol_conv3 / survey_conv3,
+                                                 "mfma_passes_per_product": PASSES[alt],
+                                                 "executed_frac": PASSES[alt] * ach * vol_conv3 / survey_conv3 / pk},
+                                    "parity": "same gates as the primary mode (tests/test_unet_gpu.py: logits <= 1e-4 rel, "
+                                              "sum|dp| < 12 per 23.6M voxels)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vols_np[0], meta, atlas, unet_sd, icon_sd)
         print(json.dumps(out), flush=True)

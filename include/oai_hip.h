@@ -133,7 +133,12 @@ void oai_unet_destroy(oai_unet* h);
 #define OAI_PREC_F32 0
 #define OAI_PREC_BF16X3 1
 #define OAI_PREC_BF16X6 2
+#define OAI_PREC_FP16X3 3 /* 2 fp16 terms (22 mantissa bits), 3 fp16 MFMA passes: fp32-grade results at the BF16X3 rate; needs
+                             activations below 65504 in magnitude (weights are range-scaled per output channel, exactly) */
 int oai_unet_set_precision(oai_unet* h, int mode);
+/* OAI_PREC_FP16X3 only: *out = 1 if, since the last reset, some activation was outside fp16's range (the results of
+ * that run are then invalid: rerun it with OAI_PREC_F32 or OAI_PREC_BF16X6).  Blocks until prior work has finished. */
+int oai_unet_range_flag(oai_unet* h, int reset, int* out);
 
 /* Bytes of device scratch oai_unet_forward_* needs for `batch` tiles of (td,th,tw). */
 size_t oai_unet_workspace_bytes(const oai_unet* h, int td, int th, int tw, int batch);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "oai_unet_create": (_I, [C.POINTER(LayerParams), _F, C.POINTER(_P)]),
     "oai_unet_destroy": (None, [_P]),
     "oai_unet_set_precision": (_I, [_P, _I]),
+    "oai_unet_range_flag": (_I, [_P, _I, C.POINTER(_I)]),
     "oai_unet_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
     "oai_unet_forward_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),

@@ -1,6 +1,7 @@
 // Host side of the segmentation path: weight ingest (reference layouts -> MFMA panels),
 // workspace planning, the layer schedule of UNet.forward (networks.py:109-149) with the
 // bit-identical dead-output trim, and the C ABI.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +21,8 @@ struct Layer {
     int kind = 0, cin = 0, cout = 0;
     int c0 = 0, c1 = 0;                 // concat split of cin (c1 = skip channels)
     float4* panel = nullptr;            // MFMA weight panel (kinds 0,1,2 except ec0)
-    float4* panel_bf[2] = {nullptr, nullptr};   // split-bf16 panels of the k3 layers, NS = 2 / 3 (built on demand)
+    float4* panel_bf[3] = {nullptr, nullptr, nullptr};   // split panels of the k3 layers: bf16 x2 terms, bf16 x3 terms, fp16 x2 terms
+    float* scale_f16 = nullptr;         // epilogue scale with the fp16 panel's per-cout power-of-two weight scaling undone
     std::vector<float> wk_host;         // canonical [27][cin][cout] weights of the k3 layers (for re-packing)
     float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
     float* scale = nullptr;
@@ -33,6 +35,7 @@ struct oai_unet {
     oai::Layer L[18];
     int variant = 0;                    // 0: MREP4/KC8, 1: MREP2/KC16
     int precision = OAI_PREC_F32;
+    int* range_flag = nullptr;          // device word set by the split-fp16 kernels when an activation exceeds fp16's range
     int n_classes = 0;
     std::vector<void*> allocs;
     bool profile = false;
@@ -97,9 +100,40 @@ static inline float bf16_to_f32(uint16_t b) {
     return f;
 }
 
+static inline uint16_t f32_to_f16_rne(float f) {            // IEEE binary16, round to nearest even, subnormals kept
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                    // rounds to >= 65520 -> inf
+    if (u < 0x33000001u) return (uint16_t)sign;                                 // < 2^-25 -> 0
+    int e = (int)(u >> 23) - 127;
+    uint32_t m = (u & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? (-14 - e) + 13 : 13;                                  // subnormal: extra shift
+    uint32_t half = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1))) ++half;
+    uint32_t out = e < -14 ? half : (((uint32_t)(e + 15) << 10) + (half - 0x400u));   // carry propagates into the exponent
+    return (uint16_t)(sign | out);
+}
+static inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 31u, m = h & 0x3ffu, u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } u = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3ffu) << 13); }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 // Split-bf16 panel of conv3_igemm_bf16s: [cb][chunk of 16][tap][term][nr][lane] x 8 bf16, where lane (half h, column j)
 // holds channels 8h..8h+7 of the chunk for cout cb*64+nr*32+j.  Terms: w = t0 + t1 (+ t2), each the RNE bf16 of the rest.
-static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int C0, int C1, int Cout, int NS) {
+// fp16: `wscale[co]` (an exact power of two) multiplies every weight of output channel co before the split.
+static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int C0, int C1, int Cout, int NS,
+                                              bool fp16 = false, const std::vector<float>* wscale = nullptr) {
     const int Cin = C0 + C1, KC = 16;
     const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
     const size_t units = ((size_t)ncb * (nch0 + nch1) * 27 + 1) * NS * 2 * 64;      // 16-byte units, +1 tap of prefetch slack
@@ -118,9 +152,12 @@ static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int 
                                 const int cl = cl0 + 8 * (lane >> 5) + j;
                                 const int co = cb * 64 + nr * 32 + (lane & 31);
                                 if (cl < Csrc && co < Cout) {
-                                    float r = wk[((size_t)t * Cin + cofs + cl) * Cout + co];
+                                    float r = wk[((size_t)t * Cin + cofs + cl) * Cout + co] * (wscale ? (*wscale)[co] : 1.0f);
                                     uint16_t b = 0;
-                                    for (int kk = 0; kk <= k; ++kk) { b = f32_to_bf16_rne(r); r -= bf16_to_f32(b); }
+                                    for (int kk = 0; kk <= k; ++kk) {
+                                        if (fp16) { b = f32_to_f16_rne(r); r -= f16_to_f32(b); }
+                                        else { b = f32_to_bf16_rne(r); r -= bf16_to_f32(b); }
+                                    }
                                     o16[u * 8 + j] = b;
                                 }
                             }
@@ -229,8 +266,9 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-    if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
-    else if (KC == 8 && h->precision == OAI_PREC_BF16X6) conv3_igemm_bf16s<3, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    else if (KC == 8 && h->precision == OAI_PREC_BF16X6) conv3_igemm_bf16s<3, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    else if (KC == 8 && h->precision == OAI_PREC_FP16X3) conv3_igemm_bf16s<2, true, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     else conv3_igemm_f32<MREP, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
     if (h->profile) {
@@ -248,9 +286,10 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     ConvArgs a;
     a.boxes = boxes;
     a.pool_out = pool_out;
+    a.range_flag = h->range_flag;
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
-    a.out = out; a.Cout = L.cout; a.scale = L.scale; a.shift = L.shift;
-    a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : 1];
+    a.out = out; a.Cout = L.cout; a.scale = h->precision == OAI_PREC_FP16X3 ? L.scale_f16 : L.scale; a.shift = L.shift;
+    a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : h->precision == OAI_PREC_BF16X6 ? 1 : 2];
     a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
     a.ncb = (L.cout + 63) / 64;
     a.relu = 1;
@@ -421,6 +460,13 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
     }
 
     oai_unet* h = new oai_unet();
+    {
+        void* f = nullptr;
+        if (hipMalloc(&f, 256) != hipSuccess) { delete h; return set_error(OAI_ERR_HIP, "oai_unet_create: hipMalloc failed"); }
+        h->allocs.push_back(f);
+        h->range_flag = reinterpret_cast<int*>(f);
+        (void)hipMemset(f, 0, 256);
+    }
     const char* env = getenv("OAI_CONV_VARIANT");
     h->variant = env ? atoi(env) : 0;
     h->n_classes = layers[DC0].cout;
@@ -465,17 +511,41 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
 
 int oai_unet_set_precision(oai_unet* h, int mode) {
     OAI_CHECK_ARG(h, "oai_unet_set_precision: null handle");
-    OAI_CHECK_ARG(mode == OAI_PREC_F32 || mode == OAI_PREC_BF16X3 || mode == OAI_PREC_BF16X6, "oai_unet_set_precision: unknown mode %d", mode);
-    OAI_CHECK_ARG(mode == OAI_PREC_F32 || h->variant == 0, "oai_unet_set_precision: split-bf16 needs OAI_CONV_VARIANT=0");
+    OAI_CHECK_ARG(mode >= OAI_PREC_F32 && mode <= OAI_PREC_FP16X3, "oai_unet_set_precision: unknown mode %d", mode);
+    OAI_CHECK_ARG(mode == OAI_PREC_F32 || h->variant == 0, "oai_unet_set_precision: split modes need OAI_CONV_VARIANT=0");
     if (mode != OAI_PREC_F32) {
-        const int slot = mode == OAI_PREC_BF16X3 ? 0 : 1, NS = slot + 2;
+        const int slot = mode == OAI_PREC_BF16X3 ? 0 : mode == OAI_PREC_BF16X6 ? 1 : 2, NS = slot == 1 ? 3 : 2;
         for (int k = 1; k < 17; ++k) {
             Layer& L = h->L[k];
             if ((L.kind != 0 && L.kind != 1) || L.panel_bf[slot]) continue;
-            if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS), &L.panel_bf[slot])) return rc;
+            if (slot < 2) {
+                if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS), &L.panel_bf[slot])) return rc;
+                continue;
+            }
+            // fp16: scale each output channel's weights by the power of two that puts max|w| in [0.5, 1) -- exact, and
+            // undone exactly by the epilogue scale -- so that the low split term stays in fp16's normal range
+            std::vector<float> ws(L.cout, 1.0f), sc(L.cout);
+            const size_t per = L.wk_host.size() / L.cout;
+            for (int co = 0; co < L.cout; ++co) {
+                float amax = 0.0f;
+                for (size_t i = 0; i < per; ++i) amax = fmaxf(amax, fabsf(L.wk_host[i * L.cout + co]));
+                if (amax > 0.0f && std::isfinite(amax)) { int e; frexpf(amax, &e); ws[co] = ldexpf(1.0f, -e); }   // amax = m 2^e, m in [0.5,1)
+            }
+            std::vector<float> host_scale(L.cout);
+            OAI_CHECK_HIP(hipMemcpy(host_scale.data(), L.scale, L.cout * sizeof(float), hipMemcpyDeviceToHost));
+            for (int co = 0; co < L.cout; ++co) sc[co] = host_scale[co] / ws[co];
+            if (int rc = upload(h, sc, &L.scale_f16)) return rc;
+            if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS, true, &ws), &L.panel_bf[slot])) return rc;
         }
     }
     h->precision = mode;
+    return OAI_OK;
+}
+
+int oai_unet_range_flag(oai_unet* h, int reset, int* out) {
+    OAI_CHECK_ARG(h && out, "oai_unet_range_flag: null pointer");
+    OAI_CHECK_HIP(hipMemcpy(out, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));     // synchronises with prior work
+    if (reset && *out) OAI_CHECK_HIP(hipMemset(h->range_flag, 0, sizeof(int)));
     return OAI_OK;
 }
 

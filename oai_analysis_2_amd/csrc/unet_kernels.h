@@ -50,6 +50,7 @@ struct ConvArgs {
     const int* boxes;                        // optional [tile][6] (lo z,y,x, hi z,y,x): the part of [lo,hi) THIS tile needs
                                              // (tiles at the volume border need less: their kept centre is partly zeroed)
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
+    int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
 };
 
 // intersection of the launch box with the tile's own box; false if the block [o, o+t) misses it entirely
@@ -262,22 +263,39 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 // ---------------------------------------------------------------------------------------------
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-template <int NS>
-__device__ __forceinline__ void split_bf16(const float4 v, bf16x4 (&t)[NS]) {
+// x = t0 + t1 (+ t2) + residual, each term the round-to-nearest 16-bit float (bf16: 8-bit mantissa; fp16: 11-bit) of
+// what the previous terms left.  With fp16 two terms carry 22 mantissa bits: 3 MFMA passes (a0b0 + a0b1 + a1b0) are
+// already fp32 grade (measured 6e-7 relative on the logits), provided |x| < 65504 (activations after ReLU / BatchNorm
+// are O(1); weights are pre-scaled per output channel by an exact power of two so that their low term stays normal).
+template <int NS, bool FP16>
+__device__ __forceinline__ void split_terms(const float4 v, u16x4 (&t)[NS]) {
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < NS; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const __bf16 b = (__bf16)r[j];            // round to nearest even (v_cvt_pk_bf16_f32)
-            t[k][j] = b;
-            r[j] -= (float)b;                           // exact in fp32
+            if constexpr (FP16) {
+                const _Float16 b = (_Float16)r[j];        // round to nearest even
+                t[k][j] = __builtin_bit_cast(unsigned short, b);
+                r[j] -= (float)b;                           // exact in fp32
+            } else {
+                const __bf16 b = (__bf16)r[j];
+                t[k][j] = __builtin_bit_cast(unsigned short, b);
+                r[j] -= (float)b;
+            }
         }
 }
 
-template <int NS, int MREP, int RX, int RY, int WY, int WX>
+template <bool FP16>
+__device__ __forceinline__ f32x16 mfma_16bit(const float4 a, const float4 b, const f32x16 c) {
+    if constexpr (FP16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NS, bool FP16, int MREP, int RX, int RY, int WY, int WX>
 __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
     static_assert(RX * RY == 32 && WY * WX == 4 && (NS == 2 || NS == 3), "bad configuration");
     constexpr int KC = 16, NREP = 2, Q = 4;
@@ -350,10 +368,14 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
             const int slot = tid + i * 256;
             const int hv = slot / Q, q = slot - hv * Q;
             if (slot < HVOX * Q) {
-                bf16x4 t[NS];
-                split_bf16<NS>(hreg[i], t);
+                u16x4 t[NS];
+                if constexpr (FP16) {      // an activation fp16 cannot hold would silently become inf: report it instead
+                    const float4 v = hreg[i];
+                    if (!(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65504.0f)) atomicOr(a.range_flag, 1);
+                }
+                split_terms<NS, FP16>(hreg[i], t);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) *reinterpret_cast<bf16x4*>(&lds[hv * REC + k * 32 + q * 8]) = t[k];
+                for (int k = 0; k < NS; ++k) *reinterpret_cast<u16x4*>(&lds[hv * REC + k * 32 + q * 8]) = t[k];
             }
         }
     };
@@ -393,9 +415,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
                     if (m >= m_lo && m < m_hi) {
 #pragma unroll
                         for (int n = 0; n < NREP; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, acur[PA[p]][m]), __builtin_bit_cast(bf16x8, bcur[PB[p]][n]),
-                                acc[m][n], 0, 0, 0);
+                            acc[m][n] = mfma_16bit<FP16>(acur[PA[p]][m], bcur[PB[p]][n], acc[m][n]);
                     }
                 }
             }

@@ -37,6 +37,8 @@ class VolumeResult:
 class VolumePipeline:
     def __init__(self, unet: UNetEngine, icon: IconEngine, atlas: Image, tile_zyx=TILE_ZYX, overlap_zyx=OVERLAP_ZYX,
                  crop_zyx=CROP_ZYX, batch: int = 32):
+        # the conv arithmetic is the engine's (UNetEngine(precision=...)); with "fp16x3" callers that keep results
+        # should check unet.range_overflow() once per volume / cohort (Segmenter3DInPatchClassWise does)
         self.unet, self.icon, self.atlas = unet, icon, atlas
         self.tile_zyx, self.overlap_zyx, self.crop_zyx, self.batch = tuple(tile_zyx), tuple(overlap_zyx), tuple(crop_zyx), batch
         self.atlas_dev = torch.from_numpy(np.ascontiguousarray(atlas.array, dtype=np.float32)).to(unet.device)

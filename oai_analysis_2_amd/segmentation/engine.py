@@ -35,7 +35,7 @@ def tile_grid(size_zyx: Sequence[int], tile_zyx: Sequence[int], overlap_zyx: Seq
 class UNetEngine:
     """The reference ``UNet`` (networks.py:38-149) as a resident set of packed weights on the GPU."""
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "fp16x3": 3}
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device=None, bn_eps: float = BN_EPS, precision: str = "f32"):
         self.lib = _lib.load()
@@ -109,6 +109,14 @@ class UNetEngine:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def range_overflow(self, reset: bool = True) -> bool:
+        """fp16x3 only: True if an activation left fp16's range since the last reset (that run must be repeated in
+        "f32" / "bf16x6").  Synchronises."""
+        out = C.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_range_flag(self._h, int(reset), C.byref(out)), "oai_unet_range_flag")
+        return bool(out.value)
 
     def tile_flops(self, tile_zyx, overlap_zyx, trimmed: bool) -> float:
         return float(self.lib.oai_unet_tile_flops(self._h, *[int(v) for v in tile_zyx], _lib.int3(overlap_zyx), int(trimmed)))

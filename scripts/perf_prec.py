@@ -9,7 +9,7 @@ tile = torch.from_numpy(make_volume(int(z["volume_seed"]), (32, 128, 128)))[None
 vol = torch.from_numpy(make_volume(0)).cuda()
 ref = z["logits_centre"]; amax = float(z["logits_abs_max"])
 eng = UNetEngine(make_unet_state_dict(0))
-for prec in ("f32", "bf16x6", "bf16x3"):
+for prec in ("f32", "bf16x6", "bf16x3", "fp16x3"):
     eng.set_precision(prec)
     got = eng.forward_tiles(tile).cpu().numpy()[0][:, 8:24, 16:112, 16:112]
     err = np.abs(got - ref).max() / amax

@@ -29,7 +29,7 @@ def test_forward_tiles_matches_reference_golden(golden_dir, bn):
     assert _rel(got, ref) < REL
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "bf16x3", "fp16x3"])
 @pytest.mark.parametrize("width_div,shape", [(4, (8, 16, 24)), (2, (16, 24, 40)), (4, (24, 40, 16))])
 def test_forward_tiles_ragged_shapes_vs_oracle(width_div, shape, precision):
     """Channel counts that are not multiples of the K chunk (8 / 16) and spatial sizes that need every strip shape."""
@@ -41,7 +41,7 @@ def test_forward_tiles_ragged_shapes_vs_oracle(width_div, shape, precision):
     assert _rel(got, ref) < REL
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "bf16x3", "fp16x3"])
 def test_full_size_tile_matches_reference_golden(golden_dir, precision):
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
     z = np.load(os.path.join(golden_dir, "unet_fulltile.npz"))
@@ -62,9 +62,9 @@ def test_full_size_tile_matches_reference_golden(golden_dir, precision):
     assert _rel(blocks, ref2) < REL
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "fp16x3"])
 def test_segment_small_matches_reference_golden(golden_dir, precision):
-    """Both fp32-grade modes must meet the reference's own acceptance test (sum|dp| < 12 per 23.6M voxels)."""
+    """All fp32-grade modes must meet the reference's own acceptance test (sum|dp| < 12 per 23.6M voxels)."""
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
     z = np.load(os.path.join(golden_dir, "segment_small.npz"))
     vol = make_volume(int(z["volume_seed"]), (24, 72, 72))
@@ -186,3 +186,20 @@ def test_sharded_pipeline_equals_unsharded_on_one_rank():
     vol = torch.from_numpy(make_volume(11, shape)).cuda()
     a, b = pipe.run(vol, Image(vol.cpu().numpy())), pipe.run_sharded(vol, Image(vol.cpu().numpy()))
     assert torch.equal(a.fc, b.fc) and torch.equal(a.tc_atlas, b.tc_atlas)
+
+
+def test_fp16x3_reports_activations_outside_fp16_range():
+    """Split-fp16 needs |activation| <= 65504; a violation is flagged (never silent) and the Segmenter reruns in fp32."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = make_unet_state_dict(seed=7, width_div=4)
+    x = torch.from_numpy(make_volume(1, (16, 32, 32)))[None, None].cuda()
+    eng = UNetEngine(sd, precision="fp16x3")
+    eng.forward_tiles(x)
+    assert not eng.range_overflow()
+    big = {k: (v * 1e6 if k == "ec0.0.weight" else v) for k, v in sd.items()}       # e0 ~ 1e6 > 65504
+    eng2 = UNetEngine(big, precision="fp16x3")
+    eng2.forward_tiles(x)
+    assert eng2.range_overflow() and not eng2.range_overflow()                          # reported once, then reset
+    eng2.set_precision("f32")
+    ref = oseg.unet_forward(x.cpu(), big).numpy()
+    assert _rel(eng2.forward_tiles(x).cpu().numpy(), ref) < REL                        # the exact mode is unaffected
