@@ -185,6 +185,33 @@ static std::vector<float> pack_up_panel(const oai_layer_params& p) {
     return out;
 }
 
+// split-fp16 panel of upconv2_igemm<true>: [N/64][Cin/16][term 2][nr 2][lane] x 8 fp16; lane (half h, column j) holds
+// channels 16*ks + 8h .. +7 for column nb*64 + nr*32 + j (column n = parity*Cout + co); weights of output channel co are
+// first multiplied by wscale[co] (exact power of two)
+static std::vector<float> pack_up_panel_f16(const float* w /*[ci][co][8]*/, int cin, int cout, const std::vector<float>& wscale) {
+    const int N = 8 * cout, nnb = (N + 63) / 64, nks = (cin + 15) / 16;
+    std::vector<float> out((size_t)nnb * nks * 4 * 64 * 4, 0.0f);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+    size_t u = 0;
+    for (int nb = 0; nb < nnb; ++nb)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int k = 0; k < 2; ++k)
+                for (int nr = 0; nr < 2; ++nr)
+                    for (int lane = 0; lane < 64; ++lane, ++u)
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = ks * 16 + 8 * (lane >> 5) + j;
+                            const int col = nb * 64 + nr * 32 + (lane & 31);
+                            if (ci < cin && col < N) {
+                                const int par = col / cout, co = col % cout;
+                                float r = w[((size_t)ci * cout + co) * 8 + par] * wscale[co];
+                                uint16_t b = 0;
+                                for (int kk = 0; kk <= k; ++kk) { b = f32_to_f16_rne(r); r -= f16_to_f32(b); }
+                                o16[u * 8 + j] = b;
+                            }
+                        }
+    return out;
+}
+
 template <typename T>
 static int upload(oai_unet* h, const std::vector<float>& v, T** dst) {
     void* d = nullptr;
@@ -322,18 +349,23 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     return OAI_OK;
 }
 
-static int launch_up(const Layer& L, const float* src, float* out, const int in_dims[3], const Box& out_need,
+static int launch_up(const oai_unet* h, const Layer& L, const float* src, float* out, const int in_dims[3], const Box& out_need,
                      int ntiles, hipStream_t st, const int* in_boxes = nullptr) {
     UpArgs a;
     a.boxes = in_boxes;
-    a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.wpanel = L.panel; a.scale = L.scale; a.shift = L.shift;
+    a.range_flag = h->range_flag;
+    const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
+    a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
+    a.wpanel = split ? L.panel_bf[2] : L.panel;
+    a.scale = split ? L.scale_f16 : L.scale;
     a.D = in_dims[0]; a.H = in_dims[1]; a.W = in_dims[2];
     for (int i = 0; i < 3; ++i) { a.lo[i] = out_need.lo[i] / 2; a.hi[i] = (out_need.hi[i] + 1) / 2; }
     const int nvox = (a.hi[0] - a.lo[0]) * (a.hi[1] - a.lo[1]) * (a.hi[2] - a.lo[2]);
     a.nmb = cdiv(nvox, 64);
     a.nnb = cdiv(8 * L.cout, 256);
     a.relu = 1;
-    upconv2_igemm_f32<<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
+    if (split) upconv2_igemm<true><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
+    else upconv2_igemm<false><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
@@ -401,13 +433,13 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     }
     RUN(launch_conv3(h, L[EC6], buf[B_P2], nullptr, buf[B_E6], d[3], need[EC6], n, st, tb(EC6)));
     RUN(launch_conv3(h, L[EC7], buf[B_E6], nullptr, buf[B_E7], d[3], need[EC7], n, st, tb(EC7)));
-    RUN(launch_up(L[DC9], buf[B_E7], buf[B_U9], d[3], need[DC9], n, st, tb(DC9)));
+    RUN(launch_up(h, L[DC9], buf[B_E7], buf[B_U9], d[3], need[DC9], n, st, tb(DC9)));
     RUN(launch_conv3(h, L[DC8], buf[B_U9], buf[B_SYN2], buf[B_D8], d[2], need[DC8], n, st, tb(DC8)));   // cat(up, skip) :127
     RUN(launch_conv3(h, L[DC7], buf[B_D8], nullptr, buf[B_D7], d[2], need[DC7], n, st, tb(DC7)));
-    RUN(launch_up(L[DC6], buf[B_D7], buf[B_U6], d[2], need[DC6], n, st, tb(DC6)));
+    RUN(launch_up(h, L[DC6], buf[B_D7], buf[B_U6], d[2], need[DC6], n, st, tb(DC6)));
     RUN(launch_conv3(h, L[DC5], buf[B_U6], buf[B_SYN1], buf[B_D5], d[1], need[DC5], n, st, tb(DC5)));   // :134
     RUN(launch_conv3(h, L[DC4], buf[B_D5], nullptr, buf[B_D4], d[1], need[DC4], n, st, tb(DC4)));
-    RUN(launch_up(L[DC3], buf[B_D4], buf[B_U3], d[1], need[DC3], n, st, tb(DC3)));
+    RUN(launch_up(h, L[DC3], buf[B_D4], buf[B_U3], d[1], need[DC3], n, st, tb(DC3)));
     RUN(launch_conv3(h, L[DC2], buf[B_U3], buf[B_SYN0], buf[B_D2], d[0], need[DC2], n, st, tb(DC2)));   // :141
     RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC1], n, st, tb(DC1)));
 #undef RUN
@@ -498,6 +530,7 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
             L.wk_host = canonical_k3(p);
             rc = upload(h, pack_conv3_panel(L.wk_host, L.c0, L.c1, p.cout, KC), &L.panel);
         } else if (p.kind == 2) {
+            L.wk_host.assign(p.weight_host, p.weight_host + (size_t)p.cin * p.cout * 8);     // [ci][co][2][2][2], for re-packing
             rc = upload(h, pack_up_panel(p), &L.panel);
         } else {
             std::vector<float> w(p.weight_host, p.weight_host + (size_t)p.cout * p.cin);
@@ -517,6 +550,20 @@ int oai_unet_set_precision(oai_unet* h, int mode) {
         const int slot = mode == OAI_PREC_BF16X3 ? 0 : mode == OAI_PREC_BF16X6 ? 1 : 2, NS = slot == 1 ? 3 : 2;
         for (int k = 1; k < 17; ++k) {
             Layer& L = h->L[k];
+            if (L.kind == 2 && slot == 2 && !L.panel_bf[2]) {      // k2s2 up-convs: split-fp16 only
+                std::vector<float> ws(L.cout, 1.0f), sc(L.cout), host_scale(L.cout);
+                for (int co = 0; co < L.cout; ++co) {
+                    float amax = 0.0f;
+                    for (int ci = 0; ci < L.cin; ++ci)
+                        for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(L.wk_host[((size_t)ci * L.cout + co) * 8 + q]));
+                    if (amax > 0.0f && std::isfinite(amax)) { int e; frexpf(amax, &e); ws[co] = ldexpf(1.0f, -e); }
+                }
+                OAI_CHECK_HIP(hipMemcpy(host_scale.data(), L.scale, L.cout * sizeof(float), hipMemcpyDeviceToHost));
+                for (int co = 0; co < L.cout; ++co) sc[co] = host_scale[co] / ws[co];
+                if (int rc = upload(h, sc, &L.scale_f16)) return rc;
+                if (int rc = upload(h, pack_up_panel_f16(L.wk_host.data(), L.cin, L.cout, ws), &L.panel_bf[2])) return rc;
+                continue;
+            }
             if ((L.kind != 0 && L.kind != 1) || L.panel_bf[slot]) continue;
             if (slot < 2) {
                 if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS), &L.panel_bf[slot])) return rc;

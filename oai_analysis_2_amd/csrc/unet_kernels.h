@@ -478,9 +478,14 @@ struct UpArgs {
     int nnb;                            // column groups of 256
     int relu;
     const int* boxes;                   // optional [tile][6]: the part of the INPUT box this tile needs
+    int* range_flag;                    // split-fp16: set when an input is outside fp16's range
 };
 
-__global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
+// SPLIT = false: exact fp32 MFMA.  SPLIT = true: split-fp16, 3 passes (see conv3_igemm_bf16s): the A rows are split in
+// registers as they arrive (each lane owns 8 consecutive channels of its row per 16-deep k step), the weight panel is
+// pre-split; the MFMA work drops 5x and the kernel becomes what it should be, bound by its output writes.
+template <bool SPLIT>
+__global__ void __launch_bounds__(256, 2) upconv2_igemm(const UpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int id = blockIdx.x;
     const int nb = id % a.nnb; id /= a.nnb;
@@ -519,6 +524,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
+  if constexpr (!SPLIT) {
     const int nkg = (a.Cin + 7) / 8;
     const float4* wp = a.wpanel + (size_t)(ncol0 / 64) * nkg * 2 * 64 + lane;
     auto load_a = [&](int kg, float4 (&af)[2]) {
@@ -532,7 +538,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) bf[n] = wp[n * 64];
     for (int kg = 0; kg < nkg; ++kg) {
-        // next k-group's fragments in flight behind this k-group's 16 MFMAs (panel has one k-group of slack)
+        // next k-group's fragments in flight behind this k-group's 16 MFMAs
         load_a(kg + 1 < nkg ? kg + 1 : kg, afn);
 #pragma unroll
         for (int n = 0; n < 2; ++n) bfn[n] = wp[((kg + 1 < nkg ? kg + 1 : kg) * 2 + n) * 64];
@@ -554,6 +560,71 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_f32(const UpArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) bf[n] = bfn[n];
     }
+  } else {
+    // k step = 16 channels; this lane's part of row m: channels 16*ks + 8*half .. +7 (ap already points at 4*half: undo)
+    const int nks = (a.Cin + 15) / 16;
+    const float4* wp = a.wpanel + (size_t)(ncol0 / 64) * nks * 4 * 64 + lane;       // [ks][term 2][nr 2][lane]
+    auto load_a = [&](int ks, float4 (&raw)[2][2]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = ks * 16 + 8 * half + 4 * q;
+                raw[m][q] = (av[m] && c < a.Cin) ? *reinterpret_cast<const float4*>(ap[m] - 4 * half + c)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    };
+    float4 raw[2][2], rawn[2][2], bf[2][2], bfn[2][2];
+    load_a(0, raw);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[k][n] = wp[(k * 2 + n) * 64];
+    constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+    for (int ks = 0; ks < nks; ++ks) {
+        const int nx = ks + 1 < nks ? ks + 1 : ks;
+        load_a(nx, rawn);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bfn[k][n] = wp[((size_t)nx * 4 + k * 2 + n) * 64];
+        // split this step's A rows: term k of row block m = 8 fp16 = one 16-byte MFMA operand
+        float4 at[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            u16x4 lo4[2], hi4[2];
+            split_terms<2, true>(raw[m][0], lo4);
+            split_terms<2, true>(raw[m][1], hi4);
+            if (!(fmaxf(fmaxf(fabsf(raw[m][0].x), fabsf(raw[m][0].y)), fmaxf(fabsf(raw[m][0].z), fabsf(raw[m][0].w))) <= 65504.0f) ||
+                !(fmaxf(fmaxf(fabsf(raw[m][1].x), fabsf(raw[m][1].y)), fmaxf(fabsf(raw[m][1].z), fabsf(raw[m][1].w))) <= 65504.0f))
+                atomicOr(a.range_flag, 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                u16x8 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = lo4[k][j]; v[4 + j] = hi4[k][j]; }
+                at[k][m] = __builtin_bit_cast(float4, v);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) raw[m][q] = rawn[m][q];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bf[k][n] = bfn[k][n];
+    }
+  }
     const int Ho = 2 * a.H, Wo = 2 * a.W;
     // rows of this lane: v = mb*64 + m*32 + 8*g + 4*half + j  (g = r>>2, j = r&3).  Decompose the 8 group bases
     // once (two integer divisions each) and walk j with carries instead of dividing per element.
