@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "unet_kernels.h"
+#include "unet_sres.h"
 
 namespace oai {
 
@@ -36,6 +37,9 @@ struct oai_unet {
     int variant = 0;                    // 0: MREP4/KC8, 1: MREP2/KC16
     int precision = OAI_PREC_F32;
     int* range_flag = nullptr;          // device word set by the split-fp16 kernels when an activation exceeds fp16's range
+    unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
+    int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (OAI_SRES_MREP=2|4)
+    bool sres = false;                  // fp16x3 runs split-resident (activations stored as fp16 term pairs, unet_sres.h)
     int n_classes = 0;
     std::vector<void*> allocs;
     bool profile = false;
@@ -258,11 +262,12 @@ enum Buf { B_E0, B_SYN0, B_P0, B_E2, B_SYN1, B_P1, B_E4, B_SYN2, B_P2, B_E6, B_E
 static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch) {
     const size_t v0 = (size_t)td * th * tw, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;
     const oai::Layer* L = h->L;
+    auto pc = [&](int k) { return (size_t)((L[k].cout + 15) / 16 * 16); };   // channels padded to whole 16-chunks (format S)
     const size_t sizes[B_COUNT] = {
-        v0 * L[EC0].cout, v0 * L[EC1].cout, v1 * L[EC1].cout, v1 * L[EC2].cout, v1 * L[EC3].cout, v2 * L[EC3].cout,
-        v2 * L[EC4].cout, v2 * L[EC5].cout, v3 * L[EC5].cout, v3 * L[EC6].cout, v3 * L[EC7].cout, v2 * L[DC9].cout,
-        v2 * L[DC8].cout, v2 * L[DC7].cout, v1 * L[DC6].cout, v1 * L[DC5].cout, v1 * L[DC4].cout, v0 * L[DC3].cout,
-        v0 * L[DC2].cout, v0 * L[DC1].cout};
+        v0 * pc(EC0), v0 * pc(EC1), v1 * pc(EC1), v1 * pc(EC2), v1 * pc(EC3), v2 * pc(EC3),
+        v2 * pc(EC4), v2 * pc(EC5), v3 * pc(EC5), v3 * pc(EC6), v3 * pc(EC7), v2 * pc(DC9),
+        v2 * pc(DC8), v2 * pc(DC7), v1 * pc(DC6), v1 * pc(DC5), v1 * pc(DC4), v0 * pc(DC3),
+        v0 * pc(DC2), v0 * pc(DC1)};
     Plan p;
     size_t o = kBoxTableBytes;          // per-tile box table of the current oai_segment_tiles call lives at the start
     for (int i = 0; i < B_COUNT; ++i) {
@@ -277,8 +282,8 @@ template <int MREP, int KC, int RX, int RY, int WY, int WX>
 static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {   // a.boxes set by the caller
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
     if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
-    const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split-bf16 kernels use 2 z slices per block
-    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? 2 : MREP);
+    const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split kernels use 2 z slices per block (4: split-resident)
+    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? h->sres_mrep : 2) : MREP);
     a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
     a.nbx = cdiv(box.hi[2] - box.lo[2], WX * RX);
     const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
@@ -293,7 +298,11 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-    if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    if (KC == 8 && h->sres) {
+        if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
+        else conv3_igemm_sres<2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
+    }
+    else if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     else if (KC == 8 && h->precision == OAI_PREC_BF16X6) conv3_igemm_bf16s<3, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     else if (KC == 8 && h->precision == OAI_PREC_FP16X3) conv3_igemm_bf16s<2, true, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     else conv3_igemm_f32<MREP, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
@@ -364,7 +373,8 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.nmb = cdiv(nvox, 64);
     a.nnb = cdiv(8 * L.cout, 256);
     a.relu = 1;
-    if (split) upconv2_igemm<true><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
+    if (split && h->sres) upconv2_igemm_sres<<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
+    else if (split) upconv2_igemm<true><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
     else upconv2_igemm<false><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
@@ -377,7 +387,17 @@ static bool pool_fusable(const oai_unet* h, const int dims[3], const Box& box) {
     return dims[0] % 4 == 0 && dims[1] % 8 == 0 && dims[2] % 16 == 0;
 }
 
-static int launch_pool(const float* in, float* out, const int dims[3], int C, int ntiles, hipStream_t st) {
+static int launch_pool(const oai_unet* h, const float* in, float* out, const int dims[3], int C, int ntiles, hipStream_t st) {
+    if (h->sres) {
+        const int nch = (C + 15) / 16;
+        const size_t total = (size_t)ntiles * (dims[0] / 2) * (dims[1] / 2) * (dims[2] / 2) * nch * 4;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        maxpool2_sres_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const unsigned char*>(in), reinterpret_cast<unsigned char*>(out),
+                                                                dims[0], dims[1], dims[2], nch, total);
+        OAI_CHECK_LAUNCH();
+        return OAI_OK;
+    }
     const size_t total4 = (size_t)ntiles * (dims[0] / 2) * (dims[1] / 2) * (dims[2] / 2) * (C / 4);
     size_t blocks = (total4 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -403,7 +423,11 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     {   // ec0 (+ gather)
         dim3 grid(cdiv(v0 / 2, 256), n);
         const int c = L[EC0].cout;
-        if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
+        unsigned char* e0s = reinterpret_cast<unsigned char*>(buf[B_E0]);
+        if (h->sres && c == 32) conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, e0s, 1, h->range_flag);
+        else if (h->sres && c == 16) conv3_first_sres_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, e0s, 1, h->range_flag);
+        else if (h->sres && c == 8) conv3_first_sres_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, e0s, 1, h->range_flag);
+        else if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
         else if (c == 16) conv3_first_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
         else if (c == 8) conv3_first_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
         else return set_error(OAI_ERR_ARG, "ec0 cout %d unsupported (8, 16 or 32)", c);
@@ -415,21 +439,21 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
         RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0]));
     } else {
         RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1)));
-        RUN(launch_pool(buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
+        RUN(launch_pool(h, buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
     }
     RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st, tb(EC2)));
     if (pool_fusable(h, d[1], need[EC3])) {
         RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3), buf[B_P1]));
     } else {
         RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3)));
-        RUN(launch_pool(buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
+        RUN(launch_pool(h, buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
     }
     RUN(launch_conv3(h, L[EC4], buf[B_P1], nullptr, buf[B_E4], d[2], need[EC4], n, st, tb(EC4)));
     if (pool_fusable(h, d[2], need[EC5])) {
         RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5), buf[B_P2]));
     } else {
         RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5)));
-        RUN(launch_pool(buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
+        RUN(launch_pool(h, buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
     }
     RUN(launch_conv3(h, L[EC6], buf[B_P2], nullptr, buf[B_E6], d[3], need[EC6], n, st, tb(EC6)));
     RUN(launch_conv3(h, L[EC7], buf[B_E6], nullptr, buf[B_E7], d[3], need[EC7], n, st, tb(EC7)));
@@ -449,6 +473,11 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
         const int kz = src.vol ? src.oz : 0, ky = src.vol ? src.oy : 0, kx = src.vol ? src.ox : 0;
         const int ez = src.vol ? src.ez : src.td, ey = src.vol ? src.ey : src.th, ex = src.vol ? src.ex : src.tw;
         dim3 grid(cdiv((size_t)bz * by * bx, 256), n);
+        if (h->sres)
+            head_sres_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const unsigned char*>(buf[B_D1]), L[DC0].cin, d[0][0], d[0][1], d[0][2],
+                                                   k.lo[0], k.lo[1], k.lo[2], bz, by, bx, kz, ky, kx, ez, ey, ex, L[DC0].plain,
+                                                   L[DC0].shift, h->n_classes, out_mode, blocks_out, tb(DC0));
+        else
         head_kernel<<<grid, 256, 0, st>>>(buf[B_D1], L[DC0].cin, d[0][0], d[0][1], d[0][2], k.lo[0], k.lo[1], k.lo[2],
                                           bz, by, bx, kz, ky, kx, ez, ey, ex, L[DC0].plain, L[DC0].shift, h->n_classes,
                                           out_mode, blocks_out, tb(DC0));
@@ -498,6 +527,11 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
         h->allocs.push_back(f);
         h->range_flag = reinterpret_cast<int*>(f);
         (void)hipMemset(f, 0, 256);
+        void* z = nullptr;
+        if (hipMalloc(&z, 256) != hipSuccess) { delete h; return set_error(OAI_ERR_HIP, "oai_unet_create: hipMalloc failed"); }
+        h->allocs.push_back(z);
+        h->zero_rec = reinterpret_cast<unsigned char*>(z);
+        (void)hipMemset(z, 0, 256);
     }
     const char* env = getenv("OAI_CONV_VARIANT");
     h->variant = env ? atoi(env) : 0;
@@ -586,6 +620,10 @@ int oai_unet_set_precision(oai_unet* h, int mode) {
         }
     }
     h->precision = mode;
+    const char* sres_env = getenv("OAI_SRES");
+    h->sres = mode == OAI_PREC_FP16X3 && !(sres_env && atoi(sres_env) == 0);
+    const char* mrep_env = getenv("OAI_SRES_MREP");
+    h->sres_mrep = mrep_env && atoi(mrep_env) == 2 ? 2 : 4;
     return OAI_OK;
 }
 

@@ -1,0 +1,533 @@
+// Split-resident fp16x3 path: activations live in HBM already split into two fp16 terms.
+//
+// Format S of a C-channel tensor:  [tile][z][y][x][C/16 chunks][2 terms][16 channels] fp16  = 4 bytes per element, the same
+// footprint as fp32, so every buffer of the fp32 path is reused as is.  x = t0 + t1 with t0 = fp16(x), t1 = fp16(x - t0)
+// (22 mantissa bits).  A (voxel, chunk) "record" is 64 contiguous bytes = four 16-byte "slots" (term, channel half) = exactly
+// the four MFMA A-operand fragments v_mfma_f32_32x32x16_f16 wants for that voxel and k-chunk.
+//
+// Why: the first fp16x3 kernel (conv3_igemm_bf16s) keeps fp32 in memory and splits every halo voxel while staging it -- once
+// per consumer workgroup and cout block, ~2.8 x ncb times per element -- and that VALU work competes with the MFMAs for
+// issue slots (profiles/r01_ablation.md).  Here each element is split ONCE, by the epilogue that produces it; staging is a
+// pure copy done by the LDS-DMA engine (global_load_lds, 16 B per lane, no VGPRs, no VALU); two workgroups share a CU so that
+// one multiplies while the other's DMA lands.
+//
+// LDS image of a halo box: record r = halo voxel (hz*HY + hy)*HX + hx at byte 64*r, its four slots XOR-swizzled by
+// key(hx) = (hx >> 2) & 3 so that the 16 lanes of a ds_read_b128 group (16 consecutive x, or 2 rows of 8) hit 16 different
+// 16-byte bank groups.  global_load_lds writes lane-linearly, so the swizzle is applied to the SOURCE address (rule 21 of the
+// CDNA guide): LDS slot p of record r receives logical slot p ^ key.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "unet_kernels.h"
+
+namespace oai {
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned split2_f16(float x, unsigned& lo_bits) {     // returns hi bits
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    lo_bits = __builtin_bit_cast(unsigned short, l);
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+__device__ __forceinline__ float join2_f16(unsigned short hi, unsigned short lo) {
+    return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
+}
+
+// Store one fp32 value per lane as its two fp16 terms into a format-S row, lanes = consecutive channels `co` of one voxel.
+// Lane pairs (co even, co+1) swap one term with a single DPP move so that every lane issues ONE dword store:
+// even lane -> (hi[co], hi[co+1]) into term 0, odd lane -> (lo[co-1], lo[co]) into term 1.
+__device__ __forceinline__ void store_split_pair(unsigned char* voxel_base /*S record row of the voxel*/, int co, float v, bool pred,
+                                                 int* range_flag) {
+    if (pred && !(fabsf(v) <= 65504.0f)) atomicOr(range_flag, 1);            // fp16 cannot hold it: report, never silently inf
+    unsigned lo;
+    const unsigned hi = split2_f16(v, lo);
+    const bool odd = co & 1;
+    const unsigned send = odd ? hi : lo;                                     // what the partner lane needs
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1 /*quad_perm 1,0,3,2*/, 0xF, 0xF, true);
+    const unsigned word = odd ? (recv | (lo << 16)) : (hi | (recv << 16));
+    if (pred)
+        *reinterpret_cast<unsigned*>(voxel_base + (co >> 4) * 64 + (odd ? 32 : 0) + ((co & 15) >> 1) * 4) = word;
+}
+
+// ---- converters (bring-up / B3 seam only): fp32 channels-last <-> format S ------------------------------------------------
+__global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, size_t nvox, int C) {
+    const int nch = (C + 15) / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvox * nch * 4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);                         // 4 channels of the chunk
+        const size_t rec = i >> 2;
+        const size_t vox = rec / nch;
+        const int ch = (int)(rec - vox * nch);
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = ch * 16 + 4 * q + j; x[j] = c < C ? in[vox * C + c] : 0.0f; }
+        u16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { unsigned l; hi[j] = (unsigned short)split2_f16(x[j], l); lo[j] = (unsigned short)l; }
+        *reinterpret_cast<u16x4*>(out + rec * 64 + q * 8) = hi;
+        *reinterpret_cast<u16x4*>(out + rec * 64 + 32 + q * 8) = lo;
+    }
+}
+
+// ---- conv3, split-resident ---------------------------------------------------------------------------------------------
+// Same decomposition as conv3_igemm_bf16s (4 waves, 2 z slices per block, two workgroups per CU so that one computes
+// while the other stages), but the halo arrives by LDS-DMA: no staging registers, no staging VALU.
+// MREP = z slices per block = accumulator row blocks per wave: 4 halves the weight-fragment bytes per MFMA (the L1 path
+// moving 4 KiB of B per wave per tap is what bounds the 3-pass kernel), at 128 accumulator VGPRs.
+template <int MREP, int RX, int RY, int WY, int WX>
+__global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+    static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4), "bad tile shape");
+    constexpr int NREP = 2, TZ = MREP;
+    constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2, HZ = TZ + 2;
+    constexpr int HVOX = HZ * HY * HX;
+    constexpr int PIECES = HVOX * 4;                            // 16-byte slots of the halo buffer
+    constexpr int NIT = (PIECES + 255) / 256;                    // LDS-DMA instructions per thread per chunk
+    constexpr int BUF = NIT * 256 * 16;                          // bytes (whole 1-KiB wave writes)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = blockIdx.x;
+    const int cb = id % a.ncb; id /= a.ncb;
+    const int bx = id % a.nbx; id /= a.nbx;
+    const int by = id % a.nby; id /= a.nby;
+    const int bz = id % a.nbz; id /= a.nbz;
+    const int tile = id;
+    const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * kTY, ox0 = a.lo[2] + bx * kTX;
+    int blo[3], bhi[3];
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + kTY <= blo[1] || ox0 >= bhi[2] || ox0 + kTX <= blo[2]) return;
+
+    const int wy = wave / WX, wx = wave % WX;
+    const int row = lane & 31, half = lane >> 5;
+    const int lx = wx * RX + row % RX, ly = wy * RY + row / RX;
+    const int m_lo = max(0, blo[0] - oz0), m_hi = min(MREP, bhi[0] - oz0);
+
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+    const unsigned char* s0 = reinterpret_cast<const unsigned char*>(a.src0) + (size_t)tile * plane * nch0 * 64;
+    const unsigned char* s1 = reinterpret_cast<const unsigned char*>(a.src1) + (size_t)tile * plane * nch1 * 64;
+
+    // ---- staging plan, once per workgroup: for each of this thread's NIT slots, the voxel it belongs to (-1 = outside the
+    // tile, i.e. Conv3d's zero padding, or beyond the halo box -> the zero record) and the logical slot it fetches
+    int pv[NIT];                     // (voxel index << 2) | swizzle key, or -1
+    const int pslot = tid & 3;       // LDS slot position of this thread's pieces (P = it*256 + tid, so P & 3 = tid & 3)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = (it * 256 + tid) >> 2;
+        const int hx = r % HX, t2 = r / HX, hy = t2 % HY, hz = t2 / HY;
+        const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+        const bool ok = r < HVOX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        pv[it] = ok ? ((((gz * a.H + gy) * a.W + gx) << 2) | ((hx >> 2) & 3)) : -1;
+    }
+    auto stage = [&](int ch) {
+        const bool first = ch < nch0;
+        const unsigned char* sb = first ? s0 : s1;
+        const int nch = first ? nch0 : nch1;
+        const int c = first ? ch : ch - nch0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const unsigned char* g = pv[it] >= 0 ? sb + ((size_t)(pv[it] >> 2) * nch + c) * 64 + ((pslot ^ (pv[it] & 3)) << 4)
+                                                 : zero_rec;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds + (it * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- A fragments: byte offset of this lane's voxel for tap (0,0,0), and its swizzled slot per dx and term
+    const unsigned char* abase = lds + (ly * HX + lx) * 64;
+    int sl[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) sl[dx][t] = ((t * 2 + half) ^ (((lx + dx) >> 2) & 3)) * 16;
+
+    constexpr int STEP = 2 * NREP * 64;                             // 16-byte units of weights per tap: [term][nr][lane]
+    const float4* wp = a.wpanel + (size_t)cb * nchunks * 27 * STEP + lane;
+    float4 bcur[2][NREP], bnext[2][NREP];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bcur[k][n] = wp[(k * NREP + n) * 64];
+    wp += STEP;
+
+    constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                                             // every wave is done reading the previous chunk
+        stage(ch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
+        __syncthreads();                                             // ... and everybody else's
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            float4 acur[2][MREP];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int m = 0; m < MREP; ++m)
+                    acur[k][m] = *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
+            wp += STEP;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) {
+                    if (m >= m_lo && m < m_hi) {
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[PA[p]][m], bcur[PB[p]][n], acc[m][n]);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
+        }
+    }
+
+    // ---- epilogue: relu(acc*scale + shift), split once, stored as format S (C/D layout: col = lane&31, rows below)
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+    const int nco = (a.Cout + 15) / 16;                               // chunks of the output tensor
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = cb * 64 + n * 32 + row;
+        const bool cvalid = co < nco * 16;                            // padded channels of the last chunk are written as 0
+        const float sc = co < a.Cout ? a.scale[co] : 0.0f, sh = co < a.Cout ? a.shift[co] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            const int oz = oz0 + m;
+            const bool zok = oz >= blo[0] && oz < bhi[0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ox = ox0 + wx * RX + rr % RX, oy = oy0 + wy * RY + rr / RX;
+                float v = acc[m][n][r] * sc + sh;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
+                store_split_pair(outb + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * nco * 64, co, v, ok, a.range_flag);
+            }
+        }
+        if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
+            if (a.pool_out) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
+                unsigned char* pb = reinterpret_cast<unsigned char*>(a.pool_out);
+                const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
+                const bool relu = a.relu != 0;
+                auto val = [&](int m, int r) { const float v = acc[m][n][r] * sc + sh; return relu ? fmaxf(v, 0.0f) : v; };
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int r0 = 4 * g + 2 * p;
+#pragma unroll
+                        for (int m = 0; m < MREP; m += 2) {
+                            float v = fmaxf(fmaxf(val(m, r0), val(m, r0 + 1)), fmaxf(val(m, r0 + 8), val(m, r0 + 9)));
+                            v = fmaxf(v, fmaxf(fmaxf(val(m + 1, r0), val(m + 1, r0 + 1)), fmaxf(val(m + 1, r0 + 8), val(m + 1, r0 + 9))));
+                            const int x = ox0 + 8 * g + 4 * half + 2 * p, y = oy0 + 2 * wy, z = oz0 + m;
+                            store_split_pair(pb + ((((size_t)tile * Dp + z / 2) * Hp + y / 2) * Wp + x / 2) * nco * 64, co, v, cvalid, a.range_flag);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// ---- k2s2 up-conv, split-resident in and out ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = blockIdx.x;
+    const int nb = id % a.nnb; id /= a.nnb;
+    const int mb = id % a.nmb; id /= a.nmb;
+    const int tile = id;
+    const int N = 8 * a.Cout;
+    const int ncol0 = nb * 256 + wave * 64;
+    if (ncol0 >= N) return;
+    const int row = lane & 31, half = lane >> 5;
+    const int rz = a.hi[0] - a.lo[0], ry = a.hi[1] - a.lo[1], rx = a.hi[2] - a.lo[2];
+    const int nvox = rz * ry * rx;
+    int blo[3], bhi[3];
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    {
+        const int zf = a.lo[0] + (mb * 64) / (rx * ry), zl = a.lo[0] + min(mb * 64 + 63, nvox - 1) / (rx * ry);
+        if (zl < blo[0] || zf >= bhi[0]) return;
+    }
+    const size_t plane = (size_t)a.D * a.H * a.W;
+    const int nks = (a.Cin + 15) / 16;
+    const unsigned char* ap[2];
+    bool av[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int v = mb * 64 + m * 32 + row;
+        av[m] = v < nvox;
+        const int vv = av[m] ? v : 0;
+        const int x = vv % rx, y = (vv / rx) % ry, z = vv / (rx * ry);
+        ap[m] = reinterpret_cast<const unsigned char*>(a.src) +
+                ((size_t)tile * plane + ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) * nks * 64 + 16 * half;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    const float4* wp = a.wpanel + (size_t)(ncol0 / 64) * nks * 4 * 64 + lane;       // [ks][term 2][nr 2][lane]
+    auto load_a = [&](int ks, float4 (&at)[2][2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                at[k][m] = av[m] ? *reinterpret_cast<const float4*>(ap[m] + ks * 64 + k * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 at[2][2], atn[2][2], bf[2][2], bfn[2][2];
+    load_a(0, at);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[k][n] = wp[(k * 2 + n) * 64];
+    constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+    for (int ks = 0; ks < nks; ++ks) {
+        const int nx = ks + 1 < nks ? ks + 1 : ks;
+        load_a(nx, atn);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bfn[k][n] = wp[((size_t)nx * 4 + k * 2 + n) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) at[k][m] = atn[k][m];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bf[k][n] = bfn[k][n];
+    }
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    const int nco = (a.Cout + 15) / 16;
+    int vx[2][4], vy[2][4], vz[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int v = mb * 64 + m * 32 + 8 * g + 4 * half;
+            vx[m][g] = v % rx;
+            const int t = v / rx;
+            vy[m][g] = t % ry;
+            vz[m][g] = t / ry;
+        }
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + (size_t)tile * 8 * plane * nco * 64;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = ncol0 + n * 32 + row;
+        const bool cok = col < N;
+        const int par = cok ? col / a.Cout : 0, co = cok ? col - par * a.Cout : 0;
+        const int pa = par >> 2, pb = (par >> 1) & 1, pc = par & 1;
+        const float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int x = vx[m][g], y = vy[m][g], z = vz[m][g];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int iz = a.lo[0] + z, iy = a.lo[1] + y, ix = a.lo[2] + x;
+                    const bool ok = cok && z < rz && iz >= blo[0] && iz < bhi[0] && iy >= blo[1] && iy < bhi[1] && ix >= blo[2] && ix < bhi[2];
+                    const int oz = 2 * iz + pa, oy = 2 * iy + pb, ox = 2 * ix + pc;
+                    float val = acc[m][n][4 * g + j] * sc + sh;
+                    if (a.relu) val = fmaxf(val, 0.0f);
+                    // lanes of a pair (co even/odd) share parity and voxel because Cout is even and 32 | lane groups
+                    store_split_pair(outb + (((size_t)oz * Ho + oy) * Wo + ox) * nco * 64, co, val, ok, a.range_flag);
+                    if (++x == rx) { x = 0; if (++y == ry) { y = 0; ++z; } }
+                }
+            }
+    }
+}
+
+// ---- ec0 (1 -> COUT, gather-fused) writing format S ---------------------------------------------------------------------------
+template <int COUT>
+__global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource s, const float* __restrict__ wk, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, unsigned char* __restrict__ out, int relu,
+                                                               int* __restrict__ range_flag) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) wl[i] = wk[i];
+    __syncthreads();
+    const size_t plane = (size_t)s.td * s.th * s.tw;
+    const int local_tile = blockIdx.y;
+    const int hw = s.tw >> 1;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= plane / 2) return;
+    const int x = 2 * (int)(p % hw), y = (int)((p / hw) % s.th), z = (int)(p / ((size_t)hw * s.th));
+    int iz[3], iy[3], ix[4];
+    const float* base;
+    if (s.vol) {
+        const int t = s.tile_begin + local_tile;
+        const int tk = t % s.gx, tj = (t / s.gx) % s.gy, ti = t / (s.gx * s.gy);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int zz = z + d - 1, yy = y + d - 1;
+            iz[d] = (unsigned)zz < (unsigned)s.td ? reflect_index(ti * s.ez + zz - s.oz, s.D) * s.H * s.W : -1;
+            iy[d] = (unsigned)yy < (unsigned)s.th ? reflect_index(tj * s.ey + yy - s.oy, s.H) * s.W : -1;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + d - 1;
+            ix[d] = (unsigned)xx < (unsigned)s.tw ? reflect_index(tk * s.ex + xx - s.ox, s.W) : -1;
+        }
+        base = s.vol;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int zz = z + d - 1, yy = y + d - 1;
+            iz[d] = (unsigned)zz < (unsigned)s.td ? zz * s.th * s.tw : -1;
+            iy[d] = (unsigned)yy < (unsigned)s.th ? yy * s.tw : -1;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + d - 1;
+            ix[d] = (unsigned)xx < (unsigned)s.tw ? xx : -1;
+        }
+        base = s.tiles + (size_t)local_tile * plane;
+    }
+    float acc[2][COUT];
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
+#pragma unroll 1
+    for (int zy = 0; zy < 9; ++zy) {
+        const int dz = zy / 3, dy = zy - 3 * dz;
+        const int a = dz == 0 ? iz[0] : dz == 1 ? iz[1] : iz[2];
+        const int b = dy == 0 ? iy[0] : dy == 1 ? iy[1] : iy[2];
+        float in[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) in[d] = (a | b | ix[d]) >= 0 ? base[(size_t)a + b + ix[d]] : 0.0f;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float* w = &wl[(zy * 3 + dx) * COUT];
+#pragma unroll
+            for (int j = 0; j < COUT; j += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(w + j);
+                acc[0][j] = fmaf(in[dx], w4.x, acc[0][j]);         acc[1][j] = fmaf(in[dx + 1], w4.x, acc[1][j]);
+                acc[0][j + 1] = fmaf(in[dx], w4.y, acc[0][j + 1]); acc[1][j + 1] = fmaf(in[dx + 1], w4.y, acc[1][j + 1]);
+                acc[0][j + 2] = fmaf(in[dx], w4.z, acc[0][j + 2]); acc[1][j + 2] = fmaf(in[dx + 1], w4.z, acc[1][j + 2]);
+                acc[0][j + 3] = fmaf(in[dx], w4.w, acc[0][j + 3]); acc[1][j + 3] = fmaf(in[dx + 1], w4.w, acc[1][j + 3]);
+            }
+        }
+    }
+    constexpr int NCH = (COUT + 15) / 16;
+    const size_t v = ((size_t)z * s.th + y) * s.tw + x;
+#pragma unroll
+    for (int vv = 0; vv < 2; ++vv) {
+        unsigned char* o = out + ((size_t)local_tile * plane + v + vv) * NCH * 64;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u16x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = ch * 16 + 4 * q + j;
+                    float r = 0.0f;
+                    if (c < COUT) { r = acc[vv][c < COUT ? c : 0] * scale[c < COUT ? c : 0] + shift[c < COUT ? c : 0]; if (relu) r = fmaxf(r, 0.0f); }
+                    if (!(fabsf(r) <= 65504.0f)) atomicOr(range_flag, 1);
+                    unsigned l;
+                    hi[j] = (unsigned short)split2_f16(r, l);
+                    lo[j] = (unsigned short)l;
+                }
+                *reinterpret_cast<u16x4*>(o + ch * 64 + q * 8) = hi;
+                *reinterpret_cast<u16x4*>(o + ch * 64 + 32 + q * 8) = lo;
+            }
+    }
+}
+
+// ---- MaxPool3d(2) on format S (fallback when the pooling cannot ride in the conv epilogue) -----------------------------------
+__global__ void __launch_bounds__(256) maxpool2_sres_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                            int D, int H, int W, int nch, size_t total /*out voxels * nch * 4*/) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);
+        size_t rec = i >> 2;
+        const int ch = (int)(rec % nch);
+        size_t v = rec / nch;
+        const int x = (int)(v % Wo); v /= Wo;
+        const int y = (int)(v % Ho); v /= Ho;
+        const int z = (int)(v % Do);
+        const size_t tile = v / Do;
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned char* p = in + ((((tile * D + 2 * z + (k >> 2)) * H + 2 * y + ((k >> 1) & 1)) * W + 2 * x + (k & 1)) * (size_t)nch + ch) * 64;
+            const u16x4 hi = *reinterpret_cast<const u16x4*>(p + q * 8), lo = *reinterpret_cast<const u16x4*>(p + 32 + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], join2_f16(hi[j], lo[j]));
+        }
+        u16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { unsigned l; hi[j] = (unsigned short)split2_f16(m[j], l); lo[j] = (unsigned short)l; }
+        *reinterpret_cast<u16x4*>(out + rec * 64 + q * 8) = hi;
+        *reinterpret_cast<u16x4*>(out + rec * 64 + 32 + q * 8) = lo;
+    }
+}
+
+// ---- head on a format-S input ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_sres_kernel(const unsigned char* __restrict__ in, int Cin, int D, int H, int W,
+                                                        int lz, int ly, int lx, int bz, int by, int bx,
+                                                        int kz, int ky, int kx, int ez, int ey, int ex,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int ncls, int out_mode, float* __restrict__ blocks, const int* __restrict__ boxes) {
+    const size_t nvox = (size_t)bz * by * bx;
+    const int tile = blockIdx.y;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvox) return;
+    const int x = lx + (int)(v % bx), y = ly + (int)((v / bx) % by), z = lz + (int)(v / ((size_t)bx * by));
+    if (boxes) {
+        const int* b = boxes + 6 * tile;
+        if (z < b[0] || z >= b[3] || y < b[1] || y >= b[4] || x < b[2] || x >= b[5]) return;
+    }
+    const int nch = (Cin + 15) / 16;
+    const unsigned char* p = in + ((((size_t)tile * D + z) * H + y) * (size_t)W + x) * nch * 64;
+    float acc[4] = {0, 0, 0, 0};
+    for (int ch = 0; ch < nch; ++ch)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u16x4 hi = *reinterpret_cast<const u16x4*>(p + ch * 64 + q * 8), lo = *reinterpret_cast<const u16x4*>(p + ch * 64 + 32 + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = ch * 16 + 4 * q + j;
+                if (c < Cin) {
+                    const float xv = join2_f16(hi[j], lo[j]);
+                    for (int k = 0; k < ncls; ++k) acc[k] = fmaf(xv, w[k * Cin + c], acc[k]);
+                }
+            }
+        }
+    const size_t evox = (size_t)ez * ey * ex;
+    const size_t o = ((size_t)(z - kz) * ey + (y - ky)) * ex + (x - kx);
+    for (int k = 0; k < ncls; ++k) {
+        const float l = acc[k] + bias[k];
+        float r = l;
+        if (out_mode != 2) {
+            const float pr = 1.0f / (1.0f + expf(-l));
+            r = out_mode == 1 ? (pr > 0.5f ? 1.0f : 0.0f) : pr;
+        }
+        blocks[((size_t)tile * ncls + k) * evox + o] = r;
+    }
+}
+
+}  // namespace oai
