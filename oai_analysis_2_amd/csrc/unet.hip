@@ -323,6 +323,7 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     a.boxes = boxes;
     a.pool_out = pool_out;
     a.range_flag = h->range_flag;
+    { static const int dbg = getenv("OAI_DBG") ? atoi(getenv("OAI_DBG")) : 0; a.dbg = dbg; }
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
     a.out = out; a.Cout = L.cout; a.scale = h->precision == OAI_PREC_FP16X3 ? L.scale_f16 : L.scale; a.shift = L.shift;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : h->precision == OAI_PREC_BF16X6 ? 1 : 2];

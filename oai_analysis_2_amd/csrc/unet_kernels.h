@@ -51,6 +51,7 @@ struct ConvArgs {
                                              // (tiles at the volume border need less: their kept centre is partly zeroed)
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
     int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
+    int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
 };
 
 // intersection of the launch box with the tile's own box; false if the block [o, o+t) misses it entirely

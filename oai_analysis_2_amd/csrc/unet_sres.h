@@ -160,31 +160,39 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
     wp += STEP;
 
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+    constexpr bool APF = MREP == 2;
+    float4 acur[2][MREP], anext[2][MREP];
+    auto load_a = [&](float4 (&dst)[2][MREP], int t) {
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+                dst[k][m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
+    };
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                             // every wave is done reading the previous chunk
-        stage(ch);
+        if (!(a.dbg & 1) || ch == 0) stage(ch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
         __syncthreads();                                             // ... and everybody else's
+        if constexpr (APF) load_a(acur, 0);
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
-            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-            float4 acur[2][MREP];
+            // A fragments: with registers to spare (MREP = 2) the NEXT tap's are fetched behind this tap's MFMAs, so that no
+            // tap starts by waiting an LDS round trip; otherwise they are read at the top of the tap (counted lgkmcnt waits)
+            if constexpr (!APF) load_a(acur, t);
+            else if (t + 1 < 27) load_a(anext, t + 1);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int m = 0; m < MREP; ++m)
-                    acur[k][m] = *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
-            wp += STEP;
+                for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
+            if (!(a.dbg & 2)) wp += STEP;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int m = 0; m < MREP; ++m) {
-                    if (m >= m_lo && m < m_hi) {
+                    if ((OAI_ABLATE & 8) || (m >= m_lo && m < m_hi)) {
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[PA[p]][m], bcur[PB[p]][n], acc[m][n]);
                     }
@@ -194,17 +202,36 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
+            if constexpr (APF) {
+                if (t + 1 < 27) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int m = 0; m < MREP; ++m) acur[k][m] = anext[k][m];
+                }
+            }
         }
     }
 
-    // ---- epilogue: relu(acc*scale + shift), split once, stored as format S (C/D layout: col = lane&31, rows below)
+    // ---- epilogue: relu(acc*scale + shift), split once, stored as format S.  The C/D layout gives a lane ONE channel of 16
+    // voxels, i.e. 4-byte pieces of 64-byte records; stored directly that is 128 dword stores per wave with 64-bit address
+    // arithmetic each (13% of the whole segmentation, profiles/r01_ablation.md).  Instead the block's output image is built in
+    // the (now idle) halo buffer, 128 B per voxel and cout half, and copied out 16 B per lane: 32 full-width stores per wave.
+    constexpr int TV = TZ * kTY * kTX;                                // voxels of the block
+    constexpr int EIT = TV * 8 / 256;                                 // 16-byte pieces per thread and cout half
+    static_assert(TV * 128 <= BUF && (TV * 8) % 256 == 0, "output image must fit the halo buffer");
+    static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0, "power-of-two block");
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int nco = (a.Cout + 15) / 16;                               // chunks of the output tensor
+    bool bad = false;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
         const bool cvalid = co < nco * 16;                            // padded channels of the last chunk are written as 0
         const float sc = co < a.Cout ? a.scale[co] : 0.0f, sh = co < a.Cout ? a.shift[co] : 0.0f;
+        const bool odd = row & 1;
+        unsigned char* lrow = lds + (row >> 4) * 64 + (odd ? 32 : 0) + ((row & 15) >> 1) * 4;
+        __syncthreads();                                              // halo reads / the previous half's copy-out are done
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
@@ -212,15 +239,33 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int ox = ox0 + wx * RX + rr % RX, oy = oy0 + wy * RY + rr / RX;
+                const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
+                const int ox = ox0 + tx, oy = oy0 + ty;
                 float v = acc[m][n][r] * sc + sh;
                 if (a.relu) v = fmaxf(v, 0.0f);
                 const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
-                store_split_pair(outb + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * nco * 64, co, v, ok, a.range_flag);
+                bad |= ok && !(fabsf(v) <= 65504.0f);                 // fp16 cannot hold it: report, never silently inf
+                unsigned lo;
+                const unsigned hi = split2_f16(v, lo);
+                const unsigned send = odd ? hi : lo;                  // lane pairs (co, co+1) swap one term: one dword each
+                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1 /*quad_perm 1,0,3,2*/, 0xF, 0xF, true);
+                *reinterpret_cast<unsigned*>(lrow + ((m * kTY + ty) * kTX + tx) * 128) = odd ? (recv | (lo << 16)) : (hi | (recv << 16));
+            }
+        }
+        __syncthreads();
+        if (!(a.dbg & 16)) {
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int sidx = it * 256 + tid, vox = sidx >> 3, q = sidx & 7;
+                const int oz = oz0 + vox / (kTX * kTY), oy = oy0 + (vox / kTX) % kTY, ox = ox0 + vox % kTX;
+                const int chunk = cb * 4 + n * 2 + (q >> 2);
+                if (chunk < nco && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1] && ox >= blo[2] && ox < bhi[2])
+                    *reinterpret_cast<float4*>(outb + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * nco * 64 + chunk * 64 + (q & 3) * 16) =
+                        *reinterpret_cast<const float4*>(lds + sidx * 16);
             }
         }
         if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
-            if (a.pool_out) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
+            if (a.pool_out && !(a.dbg & 32)) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
                 unsigned char* pb = reinterpret_cast<unsigned char*>(a.pool_out);
                 const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
                 const bool relu = a.relu != 0;
@@ -241,6 +286,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
             }
         }
     }
+    if (bad) atomicOr(a.range_flag, 1);
 }
 
 // ---- k2s2 up-conv, split-resident in and out ------------------------------------------------------------------------------

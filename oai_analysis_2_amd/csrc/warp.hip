@@ -20,7 +20,7 @@ __device__ __forceinline__ float identity_coord(int i, double inv_nm1) {
 // PyTorch grid_sampler_compute_source_index (align_corners=True) + border clip
 __device__ __forceinline__ float unnormalize_border(float c01, int size) {
     float g = c01 * 2.0f - 1.0f;                       // scale_map
-    float ix = ((g + 1.0f) * 0.5f) * (float)(size - 1);
+    float ix = (g + 1.0f) * (0.5f * (float)(size - 1));  // == ((g + 1) / 2) * (size - 1) bit for bit: the halving is exact
     return fminf((float)(size - 1), fmaxf(ix, 0.0f));
 }
 
@@ -79,23 +79,35 @@ __device__ __forceinline__ float gather8(const float* __restrict__ plane, const 
 // One lane = one output voxel.  A block is a 32(x) x 4(y) x 2(z) brick: lanes of a wave are 32 consecutive x on two
 // rows (coalesced 128-byte coordinate reads / result writes, pair loads falling in two or three lines), and the four
 // waves' source rows overlap, so the 2x2 (y,z) re-use of every source row is served by the CU's L1 instead of L2.
-template <int MODE, typename IDX>
+#ifndef OAI_WARP_U
+#define OAI_WARP_U 2
+#endif
+template <int MODE, typename IDX, int CT>
 __global__ void __launch_bounds__(kThreads)
-sample_kernel(const float* __restrict__ src, int C, int d, int h, int w,
-              const float* __restrict__ coords, int D, int H, int W, float* __restrict__ out) {
+sample_kernel(const float* __restrict__ src, int C_rt, int d, int h, int w,
+              const float* __restrict__ coords, int D, int H, int W, float* __restrict__ out, int nbx, int nby, int nbz,
+              double inz, double iny, double inx /* 1/(D-1), 1/(H-1), 1/(W-1): the identity map's spacing, from the host */) {
     const IDX plane_out = (IDX)D * H * W;
     const IDX plane_src = (IDX)d * h * w;
-    const double inz = 1.0 / (D - 1), iny = 1.0 / (H - 1), inx = 1.0 / (W - 1);
+    const int C = CT > 0 ? CT : C_rt;              // 1 (image) and 3 (field) are compiled unrolled
     const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) & 3, tz = threadIdx.x >> 7;
-    constexpr int U = 2;       // two bricks per block (z and z + half the z-bricks): their coordinate loads, then their
-                               // gathers, are in flight together.  3-D grid: no index divisions, 32-bit offsets (IDX).
-    const int x = blockIdx.x * 32 + tx, y = blockIdx.y * 4 + ty;
+    constexpr int U = OAI_WARP_U;       // z-adjacent bricks per block: their coordinate loads, then their gathers, are in
+                                        // flight together, and they share source rows in L1.  32-bit offsets (IDX).
+    // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD one contiguous run of
+    // bricks (a z-slab of the output, hence -- for the near-identity maps of registration -- of the source), so that a
+    // source line is fetched into ONE L2 instead of up to eight (17.8 -> 16.6 us on the 160^3 warp, scripts/micro/warp_probe.hip).
+    const int nb = nbx * nby * nbz;
+    const int per = (nb + 7) >> 3;
+    const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || logical >= nb) return;
+    const int bx = logical % nbx, by = (logical / nbx) % nby, bz = logical / (nbx * nby);
+    const int x = bx * 32 + tx, y = by * 4 + ty;
     IDX lin[U];
     bool ok[U];
     float cz[U], cy[U], cx[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int z = (blockIdx.z + u * gridDim.z) * 2 + tz;
+        const int z = (bz * U + u) * 2 + tz;
         ok[u] = x < W && y < H && z < D;
         lin[u] = ok[u] ? ((IDX)z * H + y) * W + x : 0;
         if (coords) {
@@ -107,6 +119,7 @@ sample_kernel(const float* __restrict__ src, int C, int d, int h, int w,
     Taps t[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) make_taps(cz[u], cy[u], cx[u], d, h, w, t[u]);
+#pragma unroll
     for (int c = 0; c < C; ++c) {
         float r[U];
 #pragma unroll
@@ -114,7 +127,7 @@ sample_kernel(const float* __restrict__ src, int C, int d, int h, int w,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (MODE == 1) r[u] += (c == 0 ? cz[u] : (c == 1 ? cy[u] : cx[u]));
-            if (ok[u]) out[c * plane_out + lin[u]] = r[u];
+            if (ok[u]) __builtin_nontemporal_store(r[u], out + c * plane_out + lin[u]);     // written once, read by a later kernel
         }
     }
 }
@@ -280,12 +293,16 @@ inline unsigned grid_for(long long work_items) {
 template <int MODE>
 int launch_sample(const float* src, int C, int d, int h, int w, const float* coords, int D, int H, int W,
                   float* out, hipStream_t s) {
-    const int nbx = (W + 31) / 32, nby = (H + 3) / 4, nbz = (D + 1) / 2;
-    if (nby > 65535 || (nbz + 1) / 2 > 65535) return oai::set_error(OAI_ERR_ARG, "volume too large for the sample grid");
-    dim3 grid(nbx, nby, (nbz + 1) / 2);
+    const int nbx = (W + 31) / 32, nby = (H + 3) / 4, nbz = ((D + 1) / 2 + OAI_WARP_U - 1) / OAI_WARP_U;
+    const long long nb = (long long)nbx * nby * nbz;
+    if (nb > (1LL << 28)) return oai::set_error(OAI_ERR_ARG, "volume too large for the sample grid");
+    const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);                  // 8 XCD runs of ceil(nb/8) bricks
     const long long big = (long long)C * D * H * W > (long long)C * d * h * w ? (long long)C * D * H * W : (long long)C * d * h * w;
-    if (big < (1LL << 31)) sample_kernel<MODE, int><<<grid, kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
-    else sample_kernel<MODE, long long><<<grid, kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out);
+    const double inz = 1.0 / (D - 1), iny = 1.0 / (H - 1), inx = 1.0 / (W - 1);
+#define OAI_SAMPLE(IDX, CT) sample_kernel<MODE, IDX, CT><<<grid, kThreads, 0, s>>>(src, C, d, h, w, coords, D, H, W, out, nbx, nby, nbz, inz, iny, inx)
+    if (big < (1LL << 31)) { if (C == 1) OAI_SAMPLE(int, 1); else if (C == 3) OAI_SAMPLE(int, 3); else OAI_SAMPLE(int, 0); }
+    else OAI_SAMPLE(long long, 0);
+#undef OAI_SAMPLE
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
