@@ -152,12 +152,16 @@ def main():
         achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         achieved_fa = achieved * vol_conv3 / survey_conv3
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
-        traffic = None            # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        def traffic_of(prec):     # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if prec == "f32" else "r01_pmc_traffic_sres.json")) as f:
+                    return json.load(f)["bytes_per_launch"] if prec in ("f32", "fp16x3") else None
+            except (OSError, KeyError, ValueError):
+                return None
+        kernel_of = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_igemm_sres (split-resident fp16x3)",
+                     "bf16x3": "conv3_igemm_bf16s (split 16-bit)", "bf16x6": "conv3_igemm_bf16s (split 16-bit)"}
+        clock_note = ("the 16-bit MFMA path is power-limited on this workload: sclk 1.96 GHz at ~1.28 kW (profiles/r01_power.md), "
+                      "i.e. a dense peak of 2.05 PFLOP/s at the clock it runs at; `peak` stays the nominal 2.5 PFLOP/s")
         out = {
             "metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32",
             "value": (world if args.mode == "replicas" else 1) * args.steps / dt, "unit": "volumes/s",
@@ -170,9 +174,10 @@ def main():
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": args.batch, "parallelism": f"{args.mode} x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if args.precision == "f32" else "conv3_igemm_bf16s (split 16-bit)",
+            "roofline": {"bound": "mfma", "kernel": kernel_of[args.precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic if args.precision == "f32" else None,   # PMC passes were run on the fp32 kernels only
+                         "traffic": traffic_of(args.precision),
+                         "clock_note": None if args.precision == "f32" else clock_note,
                          "achieved_frame_aware": achieved_fa, "frac_frame_aware": achieved_fa / peak,
                          "mfma_passes_per_product": PASSES[args.precision],
                          "executed_frac": achieved_fa * PASSES[args.precision] / peak,
@@ -205,8 +210,8 @@ def main():
             ach = survey_conv3 * n_alt / (ms_a * 1e-3) / 1e12
             pk = MFMA_F32_PEAK_TFLOPS if alt == "f32" else MFMA_BF16_PEAK_TFLOPS
             out["alt_precision"] = {"precision": alt, "value": n_alt / dta, "unit": "volumes/s", "ms_per_step": 1e3 * dta / n_alt,
-                                    "roofline": {"bound": "mfma", "kernel": "conv3_igemm_f32" if alt == "f32" else "conv3_igemm_bf16s (split 16-bit)",
-                                                 "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
+                                    "roofline": {"bound": "mfma", "kernel": kernel_of[alt],
+                                                 "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, "traffic": traffic_of(alt),
                                                  "achieved_frame_aware": ach * vol_conv3 / survey_conv3,
                                                  "mfma_passes_per_product": PASSES[alt],
                                                  "executed_frac": PASSES[alt] * ach * vol_conv3 / survey_conv3 / pk},
