@@ -371,7 +371,7 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.D = in_dims[0]; a.H = in_dims[1]; a.W = in_dims[2];
     for (int i = 0; i < 3; ++i) { a.lo[i] = out_need.lo[i] / 2; a.hi[i] = (out_need.hi[i] + 1) / 2; }
     const int nvox = (a.hi[0] - a.lo[0]) * (a.hi[1] - a.lo[1]) * (a.hi[2] - a.lo[2]);
-    a.nmb = cdiv(nvox, 64);
+    a.nmb = cdiv(nvox, split && h->sres ? 128 : 64);       // voxels per workgroup: 128 in the split-resident kernel
     a.nnb = cdiv(8 * L.cout, 256);
     a.relu = 1;
     if (split && h->sres) upconv2_igemm_sres<<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);

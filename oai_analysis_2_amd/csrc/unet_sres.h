@@ -290,45 +290,71 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
 }
 
 // ---- k2s2 up-conv, split-resident in and out ------------------------------------------------------------------------------
+// GEMM [voxels x Cin] x [Cin x 8*Cout] (column = parity * Cout + co), A rows read straight from format S, B from the
+// pre-split panel of pack_up_panel_f16.  The first version gave a workgroup 64 voxels x 256 columns with every wave
+// re-reading all 64 A rows: 37 GB of L2->L1 traffic per 32-tile pass for 5 GB of output, i.e. bound by L2 bandwidth
+// (dc9: 11.5 TB/s) at 0.7-1.6 TB/s of writes.  Now a workgroup owns 128 voxels x 256 columns as 2 x 2 waves of
+// 64 voxels x 128 columns (MREP 2, NREP 4): each A row and each B fragment is fetched by two waves of the same
+// workgroup at the same time (one L2 request), 17.6 GB per pass.
 __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char ulds[64 * 1024 + 512];      // epilogue image (64 voxels x 256 cols) + voxel table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
     int id = blockIdx.x;
     const int nb = id % a.nnb; id /= a.nnb;
     const int mb = id % a.nmb; id /= a.nmb;
     const int tile = id;
     const int N = 8 * a.Cout;
-    const int ncol0 = nb * 256 + wave * 64;
-    if (ncol0 >= N) return;
+    const int ncol0 = nb * 256 + wn * 128;
     const int row = lane & 31, half = lane >> 5;
     const int rz = a.hi[0] - a.lo[0], ry = a.hi[1] - a.lo[1], rx = a.hi[2] - a.lo[2];
     const int nvox = rz * ry * rx;
     int blo[3], bhi[3];
     if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
     {
-        const int zf = a.lo[0] + (mb * 64) / (rx * ry), zl = a.lo[0] + min(mb * 64 + 63, nvox - 1) / (rx * ry);
+        const int zf = a.lo[0] + (mb * 128) / (rx * ry), zl = a.lo[0] + min(mb * 128 + 127, nvox - 1) / (rx * ry);
         if (zl < blo[0] || zf >= bhi[0]) return;
     }
     const size_t plane = (size_t)a.D * a.H * a.W;
     const int nks = (a.Cin + 15) / 16;
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    const int nco = (a.Cout + 15) / 16;
+    unsigned* vtab = reinterpret_cast<unsigned*>(ulds + 64 * 1024);    // [128 block voxels]: output voxel index of parity 0, or ~0u
+    if (tid < 128) {
+        const int v = mb * 128 + tid;
+        unsigned e = ~0u;
+        if (v < nvox) {
+            const int x = v % rx, t = v / rx, y = t % ry, z = t / ry;
+            const int iz = a.lo[0] + z, iy = a.lo[1] + y, ix = a.lo[2] + x;
+            if (iz >= blo[0] && iz < bhi[0] && iy >= blo[1] && iy < bhi[1] && ix >= blo[2] && ix < bhi[2])
+                e = (unsigned)(((2 * iz) * Ho + 2 * iy) * Wo + 2 * ix);
+        }
+        vtab[tid] = e;
+    }
     const unsigned char* ap[2];
     bool av[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const int v = mb * 64 + m * 32 + row;
+        const int v = mb * 128 + wm * 64 + m * 32 + row;
         av[m] = v < nvox;
         const int vv = av[m] ? v : 0;
         const int x = vv % rx, y = (vv / rx) % ry, z = vv / (rx * ry);
         ap[m] = reinterpret_cast<const unsigned char*>(a.src) +
                 ((size_t)tile * plane + ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) * nks * 64 + 16 * half;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-    const float4* wp = a.wpanel + (size_t)(ncol0 / 64) * nks * 4 * 64 + lane;       // [ks][term 2][nr 2][lane]
+    // panel: [N/64 groups][ks][term 2][nr 2][lane]; this wave's four column fragments are groups g0, g0+1 (nr 0,1 each)
+    const int ngroups = (N + 63) / 64, g0 = ncol0 / 64;
+    const bool active = ncol0 < N;                                        // (the wave still helps with the copy-out)
+    const bool second = g0 + 1 < ngroups;
+    const float4* wp0 = a.wpanel + (size_t)(active ? g0 : 0) * nks * 4 * 64 + lane;
+    const float4* wp1 = a.wpanel + (size_t)(second ? g0 + 1 : (active ? g0 : 0)) * nks * 4 * 64 + lane;
     auto load_a = [&](int ks, float4 (&at)[2][2]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -336,74 +362,109 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             for (int m = 0; m < 2; ++m)
                 at[k][m] = av[m] ? *reinterpret_cast<const float4*>(ap[m] + ks * 64 + k * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    float4 at[2][2], atn[2][2], bf[2][2], bfn[2][2];
-    load_a(0, at);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bf[k][n] = wp[(k * 2 + n) * 64];
-    constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-    for (int ks = 0; ks < nks; ++ks) {
-        const int nx = ks + 1 < nks ? ks + 1 : ks;
-        load_a(nx, atn);
+    auto load_b = [&](int ks, float4 (&bt)[2][4]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bfn[k][n] = wp[((size_t)nx * 4 + k * 2 + n) * 64];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int nr = 0; nr < 2; ++nr) {
+                bt[k][nr] = wp0[((size_t)ks * 4 + k * 2 + nr) * 64];
+                bt[k][2 + nr] = wp1[((size_t)ks * 4 + k * 2 + nr) * 64];
+            }
+    };
+    if (active) {
+        float4 at[2][2], atn[2][2], bf[2][4], bfn[2][4];
+        load_a(0, at);
+        load_b(0, bf);
+        constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+        for (int ks = 0; ks < nks; ++ks) {
+            const int nx = ks + 1 < nks ? ks + 1 : ks;
+            load_a(nx, atn);
+            load_b(nx, bfn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
-        __builtin_amdgcn_sched_barrier(0);
+                    for (int n = 0; n < 4; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) at[k][m] = atn[k][m];
+                for (int m = 0; m < 2; ++m) at[k][m] = atn[k][m];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bf[k][n] = bfn[k][n];
-    }
-    const int Ho = 2 * a.H, Wo = 2 * a.W;
-    const int nco = (a.Cout + 15) / 16;
-    int vx[2][4], vy[2][4], vz[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int v = mb * 64 + m * 32 + 8 * g + 4 * half;
-            vx[m][g] = v % rx;
-            const int t = v / rx;
-            vy[m][g] = t % ry;
-            vz[m][g] = t / ry;
+                for (int n = 0; n < 4; ++n) bf[k][n] = bfn[k][n];
         }
+    }
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + (size_t)tile * 8 * plane * nco * 64;
+    if (a.Cout % 16 == 0) {
+        // ---- epilogue through LDS, one 64-voxel half (m) at a time: records [voxel 64][16 column chunks][64 B], copied out
+        // 16 B per lane: every store instruction writes whole 64-byte records, 1 KiB per wave
+        bool bad = false;
+        const int q = tid & 63;                                            // this thread's 16-byte piece of every voxel row
+        const int cg = nb * 256 + (q >> 2) * 16;                             // first global column of its record
+        const bool qok = cg < N;
+        const int par = qok ? cg / a.Cout : 0, cchunk = qok ? (cg - par * a.Cout) >> 4 : 0;
+        const unsigned poff = (unsigned)(((par >> 2) * Ho + ((par >> 1) & 1)) * Wo + (par & 1));
+        const size_t inrow = (size_t)cchunk * 64 + (q & 3) * 16;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+        for (int m = 0; m < 2; ++m) {
+            __syncthreads();                                                 // voxel table written / previous half copied out
+            if (active) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int col = ncol0 + n * 32 + row;
+                    const bool cok = col < N;
+                    const int co = cok ? col % a.Cout : 0;
+                    const float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
+                    const bool odd = row & 1;
+                    unsigned char* lrow = ulds + ((wn * 128 + n * 32 + row) >> 4) * 64 + (odd ? 32 : 0) + ((row & 15) >> 1) * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int vl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float val = acc[m][n][r] * sc + sh;
+                        if (a.relu) val = fmaxf(val, 0.0f);
+                        bad |= cok && !(fabsf(val) <= 65504.0f);
+                        unsigned lo;
+                        const unsigned hi = split2_f16(val, lo);
+                        const unsigned send = odd ? hi : lo;
+                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
+                        *reinterpret_cast<unsigned*>(lrow + vl * 1024) = odd ? (recv | (lo << 16)) : (hi | (recv << 16));
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int vl = it * 4 + (tid >> 6);                          // image row: block voxel (vl >> 5) * 64 + m * 32 + (vl & 31)
+                const unsigned e = vtab[(vl >> 5) * 64 + m * 32 + (vl & 31)];
+                if (qok && e != ~0u)
+                    *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * nco * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
+            }
+        }
+        if (bad) atomicOr(a.range_flag, 1);
+        return;
+    }
+    // ---- narrow test networks (Cout not a multiple of 16): dword stores straight from the accumulators
+    if (!active) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
         const int col = ncol0 + n * 32 + row;
         const bool cok = col < N;
         const int par = cok ? col / a.Cout : 0, co = cok ? col - par * a.Cout : 0;
-        const int pa = par >> 2, pb = (par >> 1) & 1, pc = par & 1;
         const float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
+        const unsigned poff = (unsigned)(((par >> 2) * Ho + ((par >> 1) & 1)) * Wo + (par & 1));
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int x = vx[m][g], y = vy[m][g], z = vz[m][g];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int iz = a.lo[0] + z, iy = a.lo[1] + y, ix = a.lo[2] + x;
-                    const bool ok = cok && z < rz && iz >= blo[0] && iz < bhi[0] && iy >= blo[1] && iy < bhi[1] && ix >= blo[2] && ix < bhi[2];
-                    const int oz = 2 * iz + pa, oy = 2 * iy + pb, ox = 2 * ix + pc;
-                    float val = acc[m][n][4 * g + j] * sc + sh;
-                    if (a.relu) val = fmaxf(val, 0.0f);
-                    // lanes of a pair (co even/odd) share parity and voxel because Cout is even and 32 | lane groups
-                    store_split_pair(outb + (((size_t)oz * Ho + oy) * Wo + ox) * nco * 64, co, val, ok, a.range_flag);
-                    if (++x == rx) { x = 0; if (++y == ry) { y = 0; ++z; } }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const unsigned e = vtab[wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                float val = acc[m][n][r] * sc + sh;
+                if (a.relu) val = fmaxf(val, 0.0f);
+                // lanes of a pair (co even/odd) share parity and voxel because Cout is even and 32 | lane groups
+                store_split_pair(outb + (size_t)(e == ~0u ? 0 : e + poff) * nco * 64, co, val, cok && e != ~0u, a.range_flag);
             }
     }
 }
