@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="tiles per U-Net pass (sizes the activation workspace)")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per U-Net pass (sizes the activation workspace); 0 = all that fit in 60%% of free HBM")
     ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "f32", "bf16x6", "bf16x3"],
                     help="arithmetic of the 3x3x3 conv layers.  fp16x3 (default): every fp32 operand split into two fp16 terms, "
                          "3 MFMA passes, fp32 accumulate -- fp32-grade results (same parity margins as f32 in tests/); "
@@ -104,7 +104,7 @@ def main():
     unet = UNetEngine(unet_sd, precision=args.precision)
     icon = IconEngine(icon_sd)
     atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
-    pipe = VolumePipeline(unet, icon, atlas, batch=args.batch)
+    pipe = VolumePipeline(unet, icon, atlas, batch=args.batch or None)
     n_distinct = 2
     vols_np = [make_volume((100 * rank if args.mode == "replicas" else 0) + i, VOL_SHAPE) for i in range(n_distinct)]
     vols = [torch.from_numpy(v).cuda() for v in vols_np]                  # resident in HBM before timing
@@ -173,7 +173,7 @@ def main():
                                 "fp32 activations in memory)"}[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
-                       "tiles_per_pass": args.batch, "parallelism": f"{args.mode} x{world}"},
+                       "tiles_per_pass": getattr(unet, "last_batch", args.batch), "parallelism": f"{args.mode} x{world}"},
             "roofline": {"bound": "mfma", "kernel": kernel_of[args.precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic_of(args.precision),

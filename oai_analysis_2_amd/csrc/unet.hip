@@ -318,8 +318,9 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
 // to two thin remainder strips computed with tile shapes that fit them (trimmed boxes are e.g. 18 x 98 x 98).
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
                         const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
-                        float* pool_out = nullptr) {
+                        float* pool_out = nullptr, const ConvArgs* head = nullptr) {
     ConvArgs a;
+    if (head) a = *head;                   // the fused dc0 fields (see ConvArgs); everything else is set below
     a.boxes = boxes;
     a.pool_out = pool_out;
     a.range_flag = h->range_flag;
@@ -466,13 +467,26 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     RUN(launch_conv3(h, L[DC4], buf[B_D5], nullptr, buf[B_D4], d[1], need[DC4], n, st, tb(DC4)));
     RUN(launch_up(h, L[DC3], buf[B_D4], buf[B_U3], d[1], need[DC3], n, st, tb(DC3)));
     RUN(launch_conv3(h, L[DC2], buf[B_U3], buf[B_SYN0], buf[B_D2], d[0], need[DC2], n, st, tb(DC2)));   // :141
+    // dc0 + sigmoid/threshold + centre crop: blocks are laid out over the full kept centre.  In the split-resident path it rides
+    // in dc1's epilogue (dc1's 64 output channels sit in one workgroup): no dc1 output round trip through HBM, no head launch.
+    const int kz = src.vol ? src.oz : 0, ky = src.vol ? src.oy : 0, kx = src.vol ? src.ox : 0;
+    const int ez = src.vol ? src.ez : src.td, ey = src.vol ? src.ey : src.th, ex = src.vol ? src.ex : src.tw;
+    static const bool no_fuse = getenv("OAI_NO_HEAD_FUSE") != nullptr;
+    const bool fuse_head = h->sres && !no_fuse && L[DC1].cout <= 64 && L[DC0].cin == L[DC1].cout && h->n_classes <= 4 &&
+                           need[DC1].lo[0] <= need[DC0].lo[0] && need[DC1].hi[0] >= need[DC0].hi[0];
+    if (fuse_head) {
+        ConvArgs ha;
+        ha.head_w = L[DC0].plain; ha.head_b = L[DC0].shift; ha.head_boxes = tb(DC0); ha.head_out = blocks_out;
+        ha.head_ncls = h->n_classes; ha.head_mode = out_mode;
+        ha.head_k[0] = kz; ha.head_k[1] = ky; ha.head_k[2] = kx; ha.head_e[0] = ez; ha.head_e[1] = ey; ha.head_e[2] = ex;
+        RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC0], n, st, tb(DC0), nullptr, &ha));
+        return OAI_OK;
+    }
     RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC1], n, st, tb(DC1)));
 #undef RUN
-    {   // dc0 + sigmoid/threshold + centre crop: the launch box is need[DC0]; blocks are laid out over the full kept centre
+    {
         const Box& k = need[DC0];
         const int bz = k.hi[0] - k.lo[0], by = k.hi[1] - k.lo[1], bx = k.hi[2] - k.lo[2];
-        const int kz = src.vol ? src.oz : 0, ky = src.vol ? src.oy : 0, kx = src.vol ? src.ox : 0;
-        const int ez = src.vol ? src.ez : src.td, ey = src.vol ? src.ey : src.th, ex = src.vol ? src.ex : src.tw;
         dim3 grid(cdiv((size_t)bz * by * bx, 256), n);
         if (h->sres)
             head_sres_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const unsigned char*>(buf[B_D1]), L[DC0].cin, d[0][0], d[0][1], d[0][2],

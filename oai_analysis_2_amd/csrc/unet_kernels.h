@@ -52,6 +52,14 @@ struct ConvArgs {
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
     int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
     int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
+    // split-resident kernel only: dc0 (1x1x1 conv) + sigmoid / threshold + centre crop fused into dc1's epilogue.  When head_w is
+    // set the layer's own output is NOT written; every block voxel inside head_boxes[tile] goes to the kept-centre blocks instead.
+    const float* head_w = nullptr;           // [ncls][Cout]
+    const float* head_b = nullptr;           // [ncls]
+    const int* head_boxes = nullptr;         // optional [tile][6]
+    float* head_out = nullptr;               // blocks [tile][ncls][ez][ey][ex]
+    int head_ncls = 0, head_mode = 0;        // out_mode of oai_segment_tiles: 0 probability, 1 mask, 2 logit
+    int head_k[3] = {0, 0, 0}, head_e[3] = {0, 0, 0};   // origin (in tile coordinates) and extent of a kept-centre block
 };
 
 // intersection of the launch box with the tile's own box; false if the block [o, o+t) misses it entirely

@@ -224,6 +224,13 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int nco = (a.Cout + 15) / 16;                               // chunks of the output tensor
     bool bad = false;
+    const bool head = a.head_w != nullptr;                            // uniform; host guarantees ncb == 1 and head_ncls <= 4
+    constexpr int HV = TV / 256;                                      // block voxels per thread in the fused dc0
+    float hacc[HV][4];
+#pragma unroll
+    for (int j = 0; j < HV; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hacc[j][k] = 0.0f;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
@@ -253,7 +260,30 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
             }
         }
         __syncthreads();
-        if (!(a.dbg & 16)) {
+        if (head) {
+            // dc0 on this half's 32 channels, read back from the image exactly as head_sres_kernel reads format S from
+            // memory (same join, same channel order: bit-identical logits), accumulated across the two halves
+#pragma unroll
+            for (int j = 0; j < HV; ++j) {
+                const unsigned char* rec = lds + (j * 256 + tid) * 128;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u16x4 hi = *reinterpret_cast<const u16x4*>(rec + ch * 64 + q * 8), lo = *reinterpret_cast<const u16x4*>(rec + ch * 64 + 32 + q * 8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = n * 32 + ch * 16 + 4 * q + e;
+                            if (c < a.Cout) {
+                                const float xv = join2_f16(hi[e], lo[e]);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (k < a.head_ncls) hacc[j][k] = fmaf(xv, a.head_w[k * a.Cout + c], hacc[j][k]);
+                            }
+                        }
+                    }
+            }
+        } else if (!(a.dbg & 16)) {
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
                 const int sidx = it * 256 + tid, vox = sidx >> 3, q = sidx & 7;
@@ -282,6 +312,30 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
                             const int x = ox0 + 8 * g + 4 * half + 2 * p, y = oy0 + 2 * wy, z = oz0 + m;
                             store_split_pair(pb + ((((size_t)tile * Dp + z / 2) * Hp + y / 2) * Wp + x / 2) * nco * 64, co, v, cvalid, a.range_flag);
                         }
+                    }
+            }
+        }
+    }
+    if (head) {
+        int hlo[3], hhi[3];
+        tile_box(a.head_boxes, tile, blo, bhi, hlo, hhi);
+        const size_t evox = (size_t)a.head_e[0] * a.head_e[1] * a.head_e[2];
+#pragma unroll
+        for (int j = 0; j < HV; ++j) {
+            const int vox = j * 256 + tid;
+            const int oz = oz0 + vox / (kTX * kTY), oy = oy0 + (vox / kTX) % kTY, ox = ox0 + vox % kTX;
+            if (oz >= hlo[0] && oz < hhi[0] && oy >= hlo[1] && oy < hhi[1] && ox >= hlo[2] && ox < hhi[2]) {
+                const size_t o = ((size_t)(oz - a.head_k[0]) * a.head_e[1] + (oy - a.head_k[1])) * a.head_e[2] + (ox - a.head_k[2]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < a.head_ncls) {
+                        const float l = hacc[j][k] + a.head_b[k];
+                        float r = l;
+                        if (a.head_mode != 2) {
+                            const float pr = 1.0f / (1.0f + expf(-l));
+                            r = a.head_mode == 1 ? (pr > 0.5f ? 1.0f : 0.0f) : pr;
+                        }
+                        a.head_out[((size_t)tile * a.head_ncls + k) * evox + o] = r;
                     }
             }
         }
@@ -413,6 +467,10 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
             if (active) {
+                unsigned vmask = 0;                                          // which of this lane's 16 voxel rows are real outputs
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    vmask |= (vtab[wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != ~0u ? 1u : 0u) << r;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const int col = ncol0 + n * 32 + row;
@@ -426,7 +484,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                         const int vl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         float val = acc[m][n][r] * sc + sh;
                         if (a.relu) val = fmaxf(val, 0.0f);
-                        bad |= cok && !(fabsf(val) <= 65504.0f);
+                        bad |= cok && ((vmask >> r) & 1u) && !(fabsf(val) <= 65504.0f);   // rows outside the box read unwritten memory
                         unsigned lo;
                         const unsigned hi = split2_f16(val, lo);
                         const unsigned send = odd ? hi : lo;

@@ -36,7 +36,7 @@ class VolumeResult:
 
 class VolumePipeline:
     def __init__(self, unet: UNetEngine, icon: IconEngine, atlas: Image, tile_zyx=TILE_ZYX, overlap_zyx=OVERLAP_ZYX,
-                 crop_zyx=CROP_ZYX, batch: int = 32):
+                 crop_zyx=CROP_ZYX, batch: Optional[int] = None):
         # the conv arithmetic is the engine's (UNetEngine(precision=...)); with "fp16x3" callers that keep results
         # should check unet.range_overflow() once per volume / cohort (Segmenter3DInPatchClassWise does)
         self.unet, self.icon, self.atlas = unet, icon, atlas

@@ -86,7 +86,7 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         crop_zyx = (ovl_xyz[2], ovl_xyz[0], ovl_xyz[1])        # assemble's crop_size indexing, image_transforms.py:511-512
         # batch_size of the reference config is a host-loop knob (4 tiles per H2D/D2H round trip, segmenter.py:109-119);
         # here it only sizes the activation workspace, so use a device-sized batch unless told otherwise
-        batch = int(self.config.get("device_batch_size", 32))
+        batch = int(self.config.get("device_batch_size", 0)) or None      # None: as many tiles per pass as HBM allows
         # conv arithmetic: config["precision"] in {"fp16x3" (default: fp32-grade split-fp16, 2.6x faster), "bf16x6", "f32"}
         precision = self.config.get("precision", "fp16x3")
         if eng.precision != precision:
