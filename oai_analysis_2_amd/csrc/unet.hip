@@ -38,7 +38,7 @@ struct oai_unet {
     int precision = OAI_PREC_F32;
     int* range_flag = nullptr;          // device word set by the split-fp16 kernels when an activation exceeds fp16's range
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
-    int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (OAI_SRES_MREP=2|4)
+    int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (OAI_SRES_MREP=2|4; 2 runs three workgroups per CU: -2 % on 32 border tiles, +0.5 % on the whole volume)
     bool sres = false;                  // fp16x3 runs split-resident (activations stored as fp16 term pairs, unet_sres.h)
     int n_classes = 0;
     std::vector<void*> allocs;

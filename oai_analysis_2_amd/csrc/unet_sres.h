@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
 // MREP = z slices per block = accumulator row blocks per wave: 4 halves the weight-fragment bytes per MFMA (the L1 path
 // moving 4 KiB of B per wave per tap is what bounds the 3-pass kernel), at 128 accumulator VGPRs.
 template <int MREP, int RX, int RY, int WY, int WX>
-__global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+__global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4), "bad tile shape");
     constexpr int NREP = 2, TZ = MREP;
     constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2, HZ = TZ + 2;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_sres(const ConvArgs a, con
     wp += STEP;
 
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-    constexpr bool APF = MREP == 2;
+    constexpr bool APF = false;     // A-fragment register prefetch: no gain measured (MREP 2), and it costs the third workgroup per CU
     float4 acur[2][MREP], anext[2][MREP];
     auto load_a = [&](float4 (&dst)[2][MREP], int t) {
         const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
