@@ -154,8 +154,11 @@ def main():
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
         def traffic_of(prec):     # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
             try:
+                if prec not in ("f32", "fp16x3"):
+                    return None
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if prec == "f32" else "r01_pmc_traffic_sres.json")) as f:
-                    return json.load(f)["bytes_per_launch"] if prec in ("f32", "fp16x3") else None
+                    # the counters were collected on 32-tile passes; a launch of this run covers `last_batch` tiles
+                    return json.load(f)["bytes_per_launch"] * getattr(unet, "last_batch", 32) / 32.0
             except (OSError, KeyError, ValueError):
                 return None
         kernel_of = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_igemm_sres (split-resident fp16x3)",

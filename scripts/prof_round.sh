@@ -16,7 +16,10 @@ def load(path, name):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
 f = load(O + "/fetch/f_counter_collection.csv", "FETCH_SIZE"); w = load(O + "/write/w_counter_collection.csv", "WRITE_SIZE")
-f = f[len(f) // 2:]; w = w[len(w) // 2:]           # second (warm) 32-tile pass
+def warm(rows):                                       # second (warm) 32-tile pass = from the last first-conv launch on
+    i = max(k for k, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"])
+    return rows[i:]
+f = warm(f); w = warm(w)
 lines = ["| kernel (dispatch order, warm 32-tile pass) | FETCH raw MiB | FETCH x2 MiB | WRITE MiB |", "|---|---|---|---|"]
 tot = {"conv_f": 0.0, "conv_w": 0.0, "conv_n": 0, "all_f": 0.0, "all_w": 0.0}
 for a, b in zip(f, w):
