@@ -365,6 +365,8 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     UpArgs a;
     a.boxes = in_boxes;
     a.range_flag = h->range_flag;
+    a.zero = h->zero_rec;
+    { static const int dbg = getenv("OAI_DBG") ? atoi(getenv("OAI_DBG")) : 0; a.dbg = dbg; }
     const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
     a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
     a.wpanel = split ? L.panel_bf[2] : L.panel;

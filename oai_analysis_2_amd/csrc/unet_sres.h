@@ -51,6 +51,25 @@ __device__ __forceinline__ void store_split_pair(unsigned char* voxel_base /*S r
         *reinterpret_cast<unsigned*>(voxel_base + (co >> 4) * 64 + (odd ? 32 : 0) + ((co & 15) >> 1) * 4) = word;
 }
 
+// Epilogue form of the split: a lane holds ONE channel of two voxels A, B (two C/D rows); its partner lane (lane ^ 1) holds the
+// neighbouring channel of the same voxels.  Both values are split with packed conversions, the lane pair swaps halves (one DPP
+// move + one byte permute per term), and the EVEN lane ends up with voxel A's two record words -- (hi[c], hi[c+1]) and
+// (lo[c], lo[c+1]) -- the ODD lane with voxel B's.  ~9 VALU per element instead of ~18 for two store_split_pair-style splits.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_two_voxels(float vA, float vB, unsigned sel /*odd lane 0x03020706 : even 0x05040100*/,
+                                                 unsigned& w_hi, unsigned& w_lo) {
+    const f32x2 v = {vA, vB};
+    const f16x2 hi = __builtin_convertvector(v, f16x2);
+    const f32x2 res = v - __builtin_convertvector(hi, f32x2);
+    const f16x2 lo = __builtin_convertvector(res, f16x2);
+    const unsigned H = __builtin_bit_cast(unsigned, hi), L = __builtin_bit_cast(unsigned, lo);
+    const unsigned PH = (unsigned)__builtin_amdgcn_mov_dpp((int)H, 0xB1 /*quad_perm 1,0,3,2*/, 0xF, 0xF, true);
+    const unsigned PL = (unsigned)__builtin_amdgcn_mov_dpp((int)L, 0xB1, 0xF, 0xF, true);
+    w_hi = __builtin_amdgcn_perm(PH, H, sel);
+    w_lo = __builtin_amdgcn_perm(PL, L, sel);
+}
+
 // ---- converters (bring-up / B3 seam only): fp32 channels-last <-> format S ------------------------------------------------
 __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, size_t nvox, int C) {
     const int nch = (C + 15) / 16;
@@ -223,7 +242,7 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
     static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0, "power-of-two block");
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int nco = (a.Cout + 15) / 16;                               // chunks of the output tensor
-    bool bad = false;
+    float vmax = 0.0f;
     const bool head = a.head_w != nullptr;                            // uniform; host guarantees ncb == 1 and head_ncls <= 4
     constexpr int HV = TV / 256;                                      // block voxels per thread in the fused dc0
     float hacc[HV][4];
@@ -237,26 +256,34 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
         const bool cvalid = co < nco * 16;                            // padded channels of the last chunk are written as 0
         const float sc = co < a.Cout ? a.scale[co] : 0.0f, sh = co < a.Cout ? a.shift[co] : 0.0f;
         const bool odd = row & 1;
-        unsigned char* lrow = lds + (row >> 4) * 64 + (odd ? 32 : 0) + ((row & 15) >> 1) * 4;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+        unsigned char* lrow = lds + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
         __syncthreads();                                              // halo reads / the previous half's copy-out are done
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
             const bool zok = oz >= blo[0] && oz < bhi[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
-                const int ox = ox0 + tx, oy = oy0 + ty;
-                float v = acc[m][n][r] * sc + sh;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
-                bad |= ok && !(fabsf(v) <= 65504.0f);                 // fp16 cannot hold it: report, never silently inf
-                unsigned lo;
-                const unsigned hi = split2_f16(v, lo);
-                const unsigned send = odd ? hi : lo;                  // lane pairs (co, co+1) swap one term: one dword each
-                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1 /*quad_perm 1,0,3,2*/, 0xF, 0xF, true);
-                *reinterpret_cast<unsigned*>(lrow + ((m * kTY + ty) * kTX + tx) * 128) = odd ? (recv | (lo << 16)) : (hi | (recv << 16));
+            for (int r = 0; r < 16; r += 2) {                          // C/D rows r, r+1 = x-adjacent voxels
+                float v[2];
+                int vox[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * half;
+                    const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
+                    const int ox = ox0 + tx, oy = oy0 + ty;
+                    float x = acc[m][n][r + e] * sc + sh;
+                    if (a.relu) x = fmaxf(x, 0.0f);
+                    const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
+                    v[e] = ok ? x : 0.0f;                              // voxels outside the box are never copied out
+                    vox[e] = (m * kTY + ty) * kTX + tx;
+                }
+                vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));  // fp16 range guard (checked once, below)
+                unsigned w_hi, w_lo;
+                split_two_voxels(v[0], v[1], sel, w_hi, w_lo);
+                unsigned char* dst = lrow + (odd ? vox[1] : vox[0]) * 128;
+                *reinterpret_cast<unsigned*>(dst) = w_hi;
+                *reinterpret_cast<unsigned*>(dst + 32) = w_lo;
             }
         }
         __syncthreads();
@@ -340,7 +367,7 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
             }
         }
     }
-    if (bad) atomicOr(a.range_flag, 1);
+    if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);           // fp16 cannot hold it: report, never silently inf
 }
 
 // ---- k2s2 up-conv, split-resident in and out ------------------------------------------------------------------------------
@@ -350,8 +377,13 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
 // (dc9: 11.5 TB/s) at 0.7-1.6 TB/s of writes.  Now a workgroup owns 128 voxels x 256 columns as 2 x 2 waves of
 // 64 voxels x 128 columns (MREP 2, NREP 4): each A row and each B fragment is fetched by two waves of the same
 // workgroup at the same time (one L2 request), 17.6 GB per pass.
+// Operands go through a three-stage LDS ring filled by LDS-DMA (per 16-deep k step: 128 A records = 8 KB, swizzled like the
+// conv halo, + the four 4-KiB weight slabs of the workgroup's 256 columns, already in fragment order), two steps ahead of the
+// MFMAs with counted vmcnt waits and ONE barrier per step: with direct register loads each of the 8-32 k steps waited a
+// full L2 round trip with only two waves per SIMD to hide it (1.9 TB/s of writes on dc3).
 __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char ulds[64 * 1024 + 512];      // epilogue image (64 voxels x 256 cols) + voxel table
+    constexpr int kStage = 24 * 1024, kRing = 3 * kStage;                            // [A 8 KB | B 4 x 4 KB] per stage
+    __shared__ __attribute__((aligned(16))) unsigned char ulds[kRing + 512];          // ring (the 64-KB epilogue image reuses it) + voxel table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int id = blockIdx.x;
@@ -373,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
     const int nks = (a.Cin + 15) / 16;
     const int Ho = 2 * a.H, Wo = 2 * a.W;
     const int nco = (a.Cout + 15) / 16;
-    unsigned* vtab = reinterpret_cast<unsigned*>(ulds + 64 * 1024);    // [128 block voxels]: output voxel index of parity 0, or ~0u
+    unsigned* vtab = reinterpret_cast<unsigned*>(ulds + kRing);        // [128 block voxels]: output voxel index of parity 0, or ~0u
     if (tid < 128) {
         const int v = mb * 128 + tid;
         unsigned e = ~0u;
@@ -385,17 +417,35 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         }
         vtab[tid] = e;
     }
-    const unsigned char* ap[2];
-    bool av[2];
+    // ---- DMA plan.  A: pieces p = it*256 + tid (it = 0,1) = slot (p & 3) of block voxel p >> 2; the slot holds logical slot
+    // (p & 3) ^ key(voxel) (the DMA writes lane-linearly, so the swizzle is applied to the source address).  B: piece tid of
+    // each of the four 64-column groups; a group's k-step slab [term][nr][lane] is 4 KiB contiguous in the panel.
+    const unsigned char* asrc[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int v = mb * 128 + wm * 64 + m * 32 + row;
-        av[m] = v < nvox;
-        const int vv = av[m] ? v : 0;
-        const int x = vv % rx, y = (vv / rx) % ry, z = vv / (rx * ry);
-        ap[m] = reinterpret_cast<const unsigned char*>(a.src) +
-                ((size_t)tile * plane + ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) * nks * 64 + 16 * half;
+    for (int it = 0; it < 2; ++it) {
+        const int p = it * 256 + tid, vl = p >> 2, v = mb * 128 + vl;
+        if (v < nvox) {
+            const int x = v % rx, y = (v / rx) % ry, z = v / (rx * ry);
+            asrc[it] = reinterpret_cast<const unsigned char*>(a.src) +
+                       ((size_t)tile * plane + ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) * nks * 64 + (((p & 3) ^ ((vl >> 2) & 3)) << 4);
+        } else asrc[it] = nullptr;
     }
+    const int ngroups = (N + 63) / 64;
+    const unsigned char* bsrc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        bsrc[g] = nb * 4 + g < ngroups ? reinterpret_cast<const unsigned char*>(a.wpanel + (size_t)(nb * 4 + g) * nks * 4 * 64) + tid * 16 : nullptr;
+    auto issue = [&](int st, int ks) {
+        unsigned char* base = ulds + st * kStage + wave * 1024;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[it] ? asrc[it] + ks * 64 : a.zero),
+                                             (__attribute__((address_space(3))) void*)(base + it * 4096), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[g] ? bsrc[g] + (size_t)ks * 4096 : a.zero),
+                                             (__attribute__((address_space(3))) void*)(base + 8192 + g * 4096), 16, 0, 0);
+    };
     f32x16 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -403,60 +453,47 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-    // panel: [N/64 groups][ks][term 2][nr 2][lane]; this wave's four column fragments are groups g0, g0+1 (nr 0,1 each)
-    const int ngroups = (N + 63) / 64, g0 = ncol0 / 64;
-    const bool active = ncol0 < N;                                        // (the wave still helps with the copy-out)
-    const bool second = g0 + 1 < ngroups;
-    const float4* wp0 = a.wpanel + (size_t)(active ? g0 : 0) * nks * 4 * 64 + lane;
-    const float4* wp1 = a.wpanel + (size_t)(second ? g0 + 1 : (active ? g0 : 0)) * nks * 4 * 64 + lane;
-    auto load_a = [&](int ks, float4 (&at)[2][2]) {
+    const bool active = ncol0 < N;                                        // (an idle wave still stages and copies out)
+    int aoff[2][2];                                                       // [term][m]: this lane's A slot inside a stage
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+    for (int m = 0; m < 2; ++m) {
+        const int vl = wm * 64 + m * 32 + row;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                at[k][m] = av[m] ? *reinterpret_cast<const float4*>(ap[m] + ks * 64 + k * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto load_b = [&](int ks, float4 (&bt)[2][4]) {
+        for (int k = 0; k < 2; ++k) aoff[k][m] = vl * 64 + (((k * 2 + half) ^ ((vl >> 2) & 3)) << 4);
+    }
+    const int boff = 8192 + wn * 8192 + lane * 16;                         // this wave's two column groups, fragment (k, nr) at + (k*2+nr)*1024
+    issue(0, 0);
+    if (nks > 1) issue(1, 1);
+    constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+    for (int ks = 0; ks < nks; ++ks) {
+        if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage ks landed; the younger stage may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                   // everybody's pieces of stage ks are in; stage ks-1 is read out
+        if (ks + 2 < nks && !(a.dbg & 256)) issue((ks + 2) % 3, ks + 2);
+        if (active && !(a.dbg & 128)) {
+            const unsigned char* sp = ulds + (ks % 3) * kStage;
+            float4 at[2][2], bf[2][4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
-                bt[k][nr] = wp0[((size_t)ks * 4 + k * 2 + nr) * 64];
-                bt[k][2 + nr] = wp1[((size_t)ks * 4 + k * 2 + nr) * 64];
-            }
-    };
-    if (active) {
-        float4 at[2][2], atn[2][2], bf[2][4], bfn[2][4];
-        load_a(0, at);
-        load_b(0, bf);
-        constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-        for (int ks = 0; ks < nks; ++ks) {
-            const int nx = ks + 1 < nks ? ks + 1 : ks;
-            load_a(nx, atn);
-            load_b(nx, bfn);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int m = 0; m < 2; ++m) at[k][m] = *reinterpret_cast<const float4*>(sp + aoff[k][m]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[k][n] = *reinterpret_cast<const float4*>(sp + boff + (n >> 1) * 4096 + (k * 2 + (n & 1)) * 1024);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) at[k][m] = atn[k][m];
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) bf[k][n] = bfn[k][n];
         }
     }
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + (size_t)tile * 8 * plane * nco * 64;
     if (a.Cout % 16 == 0) {
         // ---- epilogue through LDS, one 64-voxel half (m) at a time: records [voxel 64][16 column chunks][64 B], copied out
         // 16 B per lane: every store instruction writes whole 64-byte records, 1 KiB per wave
-        bool bad = false;
+        float vmax = 0.0f;
         const int q = tid & 63;                                            // this thread's 16-byte piece of every voxel row
         const int cg = nb * 256 + (q >> 2) * 16;                             // first global column of its record
         const bool qok = cg < N;
@@ -478,18 +515,23 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                     const int co = cok ? col % a.Cout : 0;
                     const float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
                     const bool odd = row & 1;
-                    unsigned char* lrow = ulds + ((wn * 128 + n * 32 + row) >> 4) * 64 + (odd ? 32 : 0) + ((row & 15) >> 1) * 4;
+                    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+                    unsigned char* lrow = ulds + ((wn * 128 + n * 32 + row) >> 4) * 64 + ((row & 15) >> 1) * 4;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int vl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float val = acc[m][n][r] * sc + sh;
-                        if (a.relu) val = fmaxf(val, 0.0f);
-                        bad |= cok && ((vmask >> r) & 1u) && !(fabsf(val) <= 65504.0f);   // rows outside the box read unwritten memory
-                        unsigned lo;
-                        const unsigned hi = split2_f16(val, lo);
-                        const unsigned send = odd ? hi : lo;
-                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
-                        *reinterpret_cast<unsigned*>(lrow + vl * 1024) = odd ? (recv | (lo << 16)) : (hi | (recv << 16));
+                    for (int r = 0; r < 16; r += 2) {
+                        float v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            float x = acc[m][n][r + e] * sc + sh;
+                            if (a.relu) x = fmaxf(x, 0.0f);
+                            v[e] = (cok && ((vmask >> (r + e)) & 1u)) ? x : 0.0f;      // rows outside the box read unwritten memory
+                        }
+                        vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                        unsigned w_hi, w_lo;
+                        split_two_voxels(v[0], v[1], sel, w_hi, w_lo);
+                        const int vl = wm * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2) + 4 * half;
+                        *reinterpret_cast<unsigned*>(lrow + vl * 1024) = w_hi;
+                        *reinterpret_cast<unsigned*>(lrow + vl * 1024 + 32) = w_lo;
                     }
                 }
             }
@@ -498,11 +540,11 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             for (int it = 0; it < 16; ++it) {
                 const int vl = it * 4 + (tid >> 6);                          // image row: block voxel (vl >> 5) * 64 + m * 32 + (vl & 31)
                 const unsigned e = vtab[(vl >> 5) * 64 + m * 32 + (vl & 31)];
-                if (qok && e != ~0u)
+                if (qok && e != ~0u && !(a.dbg & 64))
                     *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * nco * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
             }
         }
-        if (bad) atomicOr(a.range_flag, 1);
+        if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);
         return;
     }
     // ---- narrow test networks (Cout not a multiple of 16): dword stores straight from the accumulators
