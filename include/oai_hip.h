@@ -215,6 +215,33 @@ int oai_icon_forward(oai_icon* h, const float* A_dev, const float* B_dev, float*
 int oai_icon_unet_forward(oai_icon* h, int which, const float* a_dev, const float* b_dev, int D, int H, int W,
                           float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Iso-surface, smoothing, thickness distance: the step just after the hot path,
+ * oai_analysis/mesh_processing.py:298-340, 381-395.
+ *   get_mesh():      skimage.measure.marching_cubes(img, level=0.5, spacing, step_size=1)   -> oai_mc_count + oai_mc_emit
+ *                    vtkSmoothPolyDataFilter(num_iterations)                                -> oai_mesh_smooth
+ *   get_distance():  vtkDistancePolyDataFilter(SignedDistanceOff, second distance on)       -> oai_mesh_point_distance (x2)
+ * Conventions (oracle/mesh.py): volume [z][y][x]; inside = value > iso; one vertex per sign-changing grid edge, linear
+ * interpolation, (x, y, z) * spacing, ordered by owning voxel then axis; triangles wind outward (inside -> outside), ordered by
+ * cell then case-table order; the case table is face-consistent (watertight surface).
+ * ---------------------------------------------------------------------------------------- */
+/* The 256 x 16 case table (edge ids, -1 terminated) the kernels use, for cross-checks against the oracle's generator. */
+int oai_mc_table(signed char* out_256x16_host);
+size_t oai_mc_workspace_bytes(int D, int H, int W);
+/* Pass 1: classify + prefix sums into the workspace; returns the vertex and triangle counts (synchronises the stream). */
+int oai_mc_count(const float* vol_dev, int D, int H, int W, float iso, void* workspace_dev, size_t workspace_bytes,
+                 long long* n_verts_host, long long* n_tris_host, void* stream);
+/* Pass 2 (same volume, iso and workspace): verts float32 [n_verts][3], faces int32 [n_tris][3]. */
+int oai_mc_emit(const float* vol_dev, int D, int H, int W, float iso, const float spacing_xyz_host[3], const void* workspace_dev,
+                float* verts_dev, int* faces_dev, void* stream);
+/* x <- x + relaxation * (mean of edge neighbours - x), `iterations` Jacobi sweeps over the CSR edge graph
+ * (offsets [n_verts+1], neighbours); tmp and out are [n_verts][3] and distinct from the input. */
+int oai_mesh_smooth(const float* verts_in_dev, long long n_verts, const int* offsets_dev, const int* neighbours_dev,
+                    int iterations, float relaxation, float* tmp_dev, float* verts_out_dev, void* stream);
+/* dist[i] = unsigned distance from points[i] to the closest point of the triangle mesh (verts, faces). */
+int oai_mesh_point_distance(const float* points_dev, long long n_points, const float* verts_dev, const int* faces_dev,
+                            long long n_tris, float* dist_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

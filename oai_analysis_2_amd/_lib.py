@@ -45,6 +45,12 @@ SIGNATURES = {
     "oai_phi_to_itk_displacement": (_I, [_P, _I, _I, _I, _P, _P]),
     "oai_resample_through_disp": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
                                        _P, _I, _I, _I, _P]),
+    "oai_mc_table": (_I, [_P]),
+    "oai_mc_workspace_bytes": (_Z, [_I, _I, _I]),
+    "oai_mc_count": (_I, [_P, _I, _I, _I, _F, _P, _Z, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _P]),
+    "oai_mc_emit": (_I, [_P, _I, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P, _P]),
+    "oai_mesh_smooth": (_I, [_P, C.c_longlong, _P, _P, _I, _F, _P, _P, _P]),
+    "oai_mesh_point_distance": (_I, [_P, C.c_longlong, _P, _P, C.c_longlong, _P, _P]),
     "oai_image_normalize_workspace_bytes": (_Z, []),
     "oai_image_normalize": (_I, [_P, _Z, _F, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "oai_unet_create": (_I, [C.POINTER(LayerParams), _F, C.POINTER(_P)]),
