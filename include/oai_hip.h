@@ -241,6 +241,12 @@ int oai_mesh_smooth(const float* verts_in_dev, long long n_verts, const int* off
 /* dist[i] = unsigned distance from points[i] to the closest point of the triangle mesh (verts, faces). */
 int oai_mesh_point_distance(const float* points_dev, long long n_points, const float* verts_dev, const int* faces_dev,
                             long long n_tris, float* dist_dev, void* stream);
+/* Same result with a uniform-grid broad phase (cells of `cell_size` from `grid_lo`, `grid_dims` cells per axis, covering the mesh;
+ * cell_size must be >= the longest triangle edge so that a triangle touches at most 8 cells).  Synchronises once. */
+size_t oai_mesh_grid_workspace_bytes(const int grid_dims_xyz[3], long long n_tris);
+int oai_mesh_point_distance_grid(const float* points_dev, long long n_points, const float* verts_dev, const int* faces_dev,
+                                 long long n_tris, const float grid_lo_xyz_host[3], float cell_size, const int grid_dims_xyz_host[3],
+                                 void* workspace_dev, size_t workspace_bytes, float* dist_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,8 @@ SIGNATURES = {
     "oai_mc_emit": (_I, [_P, _I, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P, _P]),
     "oai_mesh_smooth": (_I, [_P, C.c_longlong, _P, _P, _I, _F, _P, _P, _P]),
     "oai_mesh_point_distance": (_I, [_P, C.c_longlong, _P, _P, C.c_longlong, _P, _P]),
+    "oai_mesh_grid_workspace_bytes": (_Z, [C.POINTER(C.c_int), C.c_longlong]),
+    "oai_mesh_point_distance_grid": (_I, [_P, C.c_longlong, _P, _P, C.c_longlong, C.POINTER(C.c_float), _F, C.POINTER(C.c_int), _P, _Z, _P, _P]),
     "oai_image_normalize_workspace_bytes": (_Z, []),
     "oai_image_normalize": (_I, [_P, _Z, _F, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "oai_unet_create": (_I, [C.POINTER(LayerParams), _F, C.POINTER(_P)]),

@@ -341,6 +341,98 @@ __global__ void __launch_bounds__(256) point_distance_kernel(const float* __rest
     if (live) dist[i] = sqrtf(best);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the same distance with a uniform-grid broad phase: triangles are binned into the cells their bounding boxes overlap
+// (count -> prefix sum -> fill), a point walks the cells around it ring by ring and stops when the best distance found is
+// within the radius already covered.  Exact (same closest-point routine, every triangle that could be closer is visited).
+// ---------------------------------------------------------------------------------------------------------------------
+struct GridDesc {
+    float lo[3];
+    float inv_h, h;
+    int n[3];
+};
+
+__device__ __forceinline__ int cell_coord(float p, float lo, float inv_h, int n) {
+    const int c = (int)floorf((p - lo) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) grid_bin_kernel(const float* __restrict__ verts, const int* __restrict__ faces, long long nt, GridDesc g,
+                                                       int* __restrict__ cell_count /*FILL: running fill cursor*/, const int* __restrict__ cell_start,
+                                                       int* __restrict__ tri_list) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    int lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = verts[3 * (long long)faces[3 * t] + k], b = verts[3 * (long long)faces[3 * t + 1] + k], c = verts[3 * (long long)faces[3 * t + 2] + k];
+        lo[k] = cell_coord(fminf(a, fminf(b, c)), g.lo[k], g.inv_h, g.n[k]);
+        hi[k] = cell_coord(fmaxf(a, fmaxf(b, c)), g.lo[k], g.inv_h, g.n[k]);
+    }
+    for (int z = lo[2]; z <= hi[2]; ++z)
+        for (int y = lo[1]; y <= hi[1]; ++y)
+            for (int x = lo[0]; x <= hi[0]; ++x) {
+                const int cell = (z * g.n[1] + y) * g.n[0] + x;
+                const int slot = atomicAdd(&cell_count[cell], 1);
+                if (FILL) tri_list[cell_start[cell] + slot] = (int)t;
+            }
+}
+
+__global__ void __launch_bounds__(256) grid_distance_kernel(const float* __restrict__ pts, long long np, const float* __restrict__ verts,
+                                                            const int* __restrict__ faces, GridDesc g, const int* __restrict__ cell_start,
+                                                            const int* __restrict__ tri_list, float* __restrict__ dist) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    const V3 p = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    const int cx = cell_coord(p.x, g.lo[0], g.inv_h, g.n[0]), cy = cell_coord(p.y, g.lo[1], g.inv_h, g.n[1]), cz = cell_coord(p.z, g.lo[2], g.inv_h, g.n[2]);
+    const int rmax = max(max(max(cx, g.n[0] - 1 - cx), max(cy, g.n[1] - 1 - cy)), max(cz, g.n[2] - 1 - cz));
+    float best = 3.4e38f;
+    for (int r = 0; r <= rmax; ++r) {
+        // triangles not visited after ring r-1 lie in cells at Chebyshev distance >= r: at least (r-1) * h away from the point's
+        // projection onto the grid box, hence from the point
+        const float covered = (float)(r - 1) * g.h;
+        if (r > 0 && best <= covered * covered) break;
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, g.n[2] - 1), y0 = max(cy - r, 0), y1 = min(cy + r, g.n[1] - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.n[0] - 1);
+        auto visit = [&](int x, int y, int z) {
+            const int cell = (z * g.n[1] + y) * g.n[0] + x;
+            for (int k = cell_start[cell]; k < cell_start[cell + 1]; ++k) {
+                const int* f = faces + 3 * (long long)tri_list[k];
+                const float* a = verts + 3 * (long long)f[0];
+                const float* b = verts + 3 * (long long)f[1];
+                const float* c = verts + 3 * (long long)f[2];
+                const V3 A = {a[0], a[1], a[2]};
+                best = fminf(best, tri_dist2(p, A, V3{b[0], b[1], b[2]} - A, V3{c[0], c[1], c[2]} - A));
+            }
+        };
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                if (z == cz - r || z == cz + r || y == cy - r || y == cy + r) {      // a face of the ring's cube: the whole row
+                    for (int x = x0; x <= x1; ++x) visit(x, y, z);
+                } else {                                                             // otherwise only the two end cells are new
+                    if (cx - r >= 0) visit(cx - r, y, z);
+                    if (cx + r < g.n[0]) visit(cx + r, y, z);
+                }
+            }
+    }
+    dist[i] = sqrtf(best);
+}
+
+struct GridLayout { size_t count, start, list, scratch, total; };
+GridLayout grid_layout(long long ncells, long long nt) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    GridLayout l;
+    size_t o = 0;
+    l.count = o; o += al((size_t)(ncells + 1) * 4);
+    l.start = o; o += al((size_t)(ncells + 1) * 4);
+    l.list = o; o += al((size_t)nt * 8 * 4);
+    l.scratch = o; o += al(scan_scratch_ints(ncells + 1) * 4);
+    l.total = o;
+    return l;
+}
+
 struct McLayout {
     size_t flags, vcount, tcount, voff, toff, scratch, total;
 };
@@ -443,6 +535,45 @@ int oai_mesh_point_distance(const float* points_dev, long long n_points, const f
     OAI_CHECK_ARG(n_points >= 0 && n_tris > 0, "oai_mesh_point_distance: needs at least one triangle");
     if (n_points == 0) return OAI_OK;
     point_distance_kernel<<<oai::cdiv(n_points, 256), 256, 0, (hipStream_t)stream>>>(points_dev, n_points, verts_dev, faces_dev, n_tris, dist_dev);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+size_t oai_mesh_grid_workspace_bytes(const int grid_dims_xyz[3], long long n_tris) {
+    if (!grid_dims_xyz || n_tris <= 0) return 0;
+    return grid_layout((long long)grid_dims_xyz[0] * grid_dims_xyz[1] * grid_dims_xyz[2], n_tris).total;
+}
+
+int oai_mesh_point_distance_grid(const float* points_dev, long long n_points, const float* verts_dev, const int* faces_dev, long long n_tris,
+                                 const float grid_lo_xyz[3], float cell_size, const int grid_dims_xyz[3],
+                                 void* workspace_dev, size_t workspace_bytes, float* dist_dev, void* stream) {
+    OAI_CHECK_ARG(points_dev && verts_dev && faces_dev && dist_dev && grid_lo_xyz && grid_dims_xyz && workspace_dev, "oai_mesh_point_distance_grid: null pointer");
+    OAI_CHECK_ARG(n_points >= 0 && n_tris > 0 && cell_size > 0.0f, "oai_mesh_point_distance_grid: needs triangles and a positive cell size");
+    OAI_CHECK_ARG(grid_dims_xyz[0] > 0 && grid_dims_xyz[1] > 0 && grid_dims_xyz[2] > 0, "oai_mesh_point_distance_grid: empty grid");
+    const long long ncells = (long long)grid_dims_xyz[0] * grid_dims_xyz[1] * grid_dims_xyz[2];
+    OAI_CHECK_ARG(ncells < (1LL << 30), "oai_mesh_point_distance_grid: grid too fine");
+    const GridLayout l = grid_layout(ncells, n_tris);
+    if (workspace_bytes < l.total) return oai::set_error(OAI_ERR_WORKSPACE, "oai_mesh_point_distance_grid: workspace %zu B < %zu B", workspace_bytes, l.total);
+    if (n_points == 0) return OAI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace_dev;
+    int* count = (int*)(ws + l.count); int* start = (int*)(ws + l.start); int* list = (int*)(ws + l.list);
+    GridDesc g;
+    for (int k = 0; k < 3; ++k) { g.lo[k] = grid_lo_xyz[k]; g.n[k] = grid_dims_xyz[k]; }
+    g.h = cell_size; g.inv_h = 1.0f / cell_size;
+    OAI_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)(ncells + 1) * 4, st));
+    grid_bin_kernel<false><<<oai::cdiv(n_tris, 256), 256, 0, st>>>(verts_dev, faces_dev, n_tris, g, count, nullptr, nullptr);
+    OAI_CHECK_LAUNCH();
+    if (int rc = exclusive_scan(count, start, ncells + 1, (int*)(ws + l.scratch), st)) return rc;
+    int total = 0;
+    OAI_CHECK_HIP(hipMemcpyAsync(&total, start + ncells, 4, hipMemcpyDeviceToHost, st));
+    OAI_CHECK_HIP(hipStreamSynchronize(st));
+    if ((long long)total > n_tris * 8)          // a triangle longer than a cell overlaps more than 8 cells: the caller's cell size is too small
+        return oai::set_error(OAI_ERR_ARG, "oai_mesh_point_distance_grid: %d triangle-cell pairs > 8 per triangle; cell_size must be >= the longest edge", total);
+    OAI_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)(ncells + 1) * 4, st));
+    grid_bin_kernel<true><<<oai::cdiv(n_tris, 256), 256, 0, st>>>(verts_dev, faces_dev, n_tris, g, count, start, list);
+    OAI_CHECK_LAUNCH();
+    grid_distance_kernel<<<oai::cdiv(n_points, 256), 256, 0, st>>>(points_dev, n_points, verts_dev, faces_dev, g, start, list, dist_dev);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }

@@ -231,13 +231,28 @@ def split_mesh(mesh: Mesh, mesh_type: str = "FC") -> Tuple[Mesh, Mesh]:
 
 
 # ---- thickness -----------------------------------------------------------------------------------------------------------------
-def point_distance(points: np.ndarray, mesh: Mesh) -> np.ndarray:
+def point_distance(points: np.ndarray, mesh: Mesh, broad_phase: bool = True) -> np.ndarray:
+    """Unsigned distance from each point to the mesh surface.  ``broad_phase``: bin the triangles into a uniform grid whose cell is
+    the longest triangle edge (>= 2 voxels' worth) so that a point only tests the triangles around it; False = brute force."""
     lib = _lib.load()
     p, v, f = _dev(points, np.float32), _dev(mesh.verts, np.float32), _dev(mesh.faces, np.int32)
     out = torch.empty(len(points), dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
-        _lib.check(lib.oai_mesh_point_distance(p.data_ptr(), len(points), v.data_ptr(), f.data_ptr(), len(mesh.faces), out.data_ptr(), _stream()),
-                   "oai_mesh_point_distance")
+        if broad_phase and len(mesh.faces) > 0:
+            tri = mesh.verts[mesh.faces].astype(np.float64)
+            edge = max(np.linalg.norm(tri[:, 0] - tri[:, 1], axis=1).max(), np.linalg.norm(tri[:, 1] - tri[:, 2], axis=1).max(),
+                       np.linalg.norm(tri[:, 2] - tri[:, 0], axis=1).max())
+            lo, hi = mesh.verts.min(axis=0).astype(np.float64), mesh.verts.max(axis=0).astype(np.float64)
+            h = max(float(edge) * 1.0001, float((hi - lo).max()) / 512.0, 1e-6)              # at most 512 cells per axis
+            dims = np.maximum(np.ceil((hi - lo) / h).astype(np.int64) + 1, 1)
+            glo = (C.c_float * 3)(*[float(x) for x in lo - 0.5 * h * 1e-3])
+            gd = (C.c_int * 3)(*[int(x) for x in dims])
+            ws = torch.empty(int(lib.oai_mesh_grid_workspace_bytes(gd, len(mesh.faces))), dtype=torch.uint8, device=p.device)
+            _lib.check(lib.oai_mesh_point_distance_grid(p.data_ptr(), len(points), v.data_ptr(), f.data_ptr(), len(mesh.faces), glo, float(h), gd,
+                                                        ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()), "oai_mesh_point_distance_grid")
+        else:
+            _lib.check(lib.oai_mesh_point_distance(p.data_ptr(), len(points), v.data_ptr(), f.data_ptr(), len(mesh.faces), out.data_ptr(), _stream()),
+                       "oai_mesh_point_distance")
     return out.cpu().numpy()
 
 

@@ -54,9 +54,12 @@ def test_point_distance_matches_oracle():
     pts = np.concatenate([v[:300] + rng.normal(size=(300, 3)).astype(np.float32) * 2.0,          # near the surface: all Voronoi regions
                           rng.uniform(0, 34, size=(300, 3)).astype(np.float32), v[:50]])
     ref = om.distance_to_mesh(pts, v, f)
-    got = mp.point_distance(pts, mp.Mesh(v, f))
-    assert np.abs(got - ref).max() < 1e-4 * max(1.0, ref.max())
-    assert np.abs(got[-50:]).max() < 1e-3                                                        # mesh vertices lie on the mesh
+    for broad in (False, True):                                                                  # brute force / uniform-grid broad phase
+        got = mp.point_distance(pts, mp.Mesh(v, f), broad_phase=broad)
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, ref.max()), broad
+        assert np.abs(got[-50:]).max() < 1e-3                                                    # mesh vertices lie on the mesh
+    far = (rng.uniform(-200, 200, size=(64, 3))).astype(np.float32)                              # far outside the grid: every ring is walked
+    assert np.allclose(mp.point_distance(far, mp.Mesh(v, f), True), mp.point_distance(far, mp.Mesh(v, f), False), rtol=1e-6)
 
 
 def test_thickness_of_a_shell():
