@@ -82,3 +82,7 @@ def test_thickness_of_a_shell():
     med = np.median(d_in.point_data["Distance"])
     assert abs(med - T) < 1.5, med                                   # plate thickness, up to smoothing and the rim
     assert d_out.point_data["Distance"].shape == (outer.GetNumberOfPoints(),)
+    # the Dask task body (dask_processing.py:114-122) is the same chain with the reference's defaults
+    from oai_analysis_2_amd.dask_processing import get_thickness
+    inner_d = get_thickness(img, "TC")
+    assert abs(np.median(inner_d.point_data["Distance"]) - T) < 1.5 and inner_d.GetNumberOfPoints() > 500
