@@ -22,6 +22,7 @@ constexpr int kUpIn[5] = {48, 96, 192, 512, 512};
 constexpr float kLeaky = 0.01f;
 constexpr float kBnEps = 1e-5f;
 constexpr long long kSplitKBelow = 16384;     // output voxels (per launch / per parity class) below which K is split over threads
+constexpr long long kFewBlocks = 1024;        // split-K launches with fewer workgroups than this use 4 couts per block (4x the blocks)
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : v * kLeaky; }
 
@@ -263,11 +264,21 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
             icon_conv3_kernel<2, 16, true, true, 1><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
                                                                            nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
                                                                            dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
-        } else {
+        } else if ((long long)oai::cdiv(dm.vox[l + 1], 32) * (kDown[l + 1] / 16) >= kFewBlocks) {
             dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1] / 16);
             icon_conv3_kernel<2, 16, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
                                                                            nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
                                                                            dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+        } else if ((long long)oai::cdiv(dm.vox[l + 1], 32) * (kDown[l + 1] / 16) < kFewBlocks / 16) {
+            dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1]);          // one cout per block
+            icon_conv3_kernel<2, 1, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
+                                                                          nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
+                                                                          dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+        } else {        // the deepest levels (a few dozen voxels): 4 couts per block instead of 16, four times the blocks
+            dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1] / 4);
+            icon_conv3_kernel<2, 4, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
+                                                                          nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
+                                                                          dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
         }
         OAI_CHECK_LAUNCH();
     }
@@ -279,11 +290,21 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
             icon_up_kernel<16, 1><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
                                                          nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
                                                          dm.d[l][0], dm.d[l][1], dm.d[l][2]);
-        } else {
+        } else if ((long long)oai::cdiv(per_par, 32) * (kUpOut[l] / 16) * 8 >= kFewBlocks) {
             dim3 grid(oai::cdiv(per_par, 32), kUpOut[l] / 16, 8);
             icon_up_kernel<16, 8><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
                                                          nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
                                                          dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        } else if ((long long)oai::cdiv(per_par, 32) * (kUpOut[l] / 16) * 8 < kFewBlocks / 16) {
+            dim3 grid(oai::cdiv(per_par, 32), kUpOut[l], 8);
+            icon_up_kernel<1, 8><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                        nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                        dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        } else {
+            dim3 grid(oai::cdiv(per_par, 32), kUpOut[l] / 4, 8);
+            icon_up_kernel<4, 8><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                        nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                        dm.d[l][0], dm.d[l][1], dm.d[l][2]);
         }
         OAI_CHECK_LAUNCH();
     }
