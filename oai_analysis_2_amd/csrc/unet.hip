@@ -38,6 +38,8 @@ struct oai_unet {
     int precision = OAI_PREC_F32;
     int* range_flag = nullptr;          // device word set by the split-fp16 kernels when an activation exceeds fp16's range
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
+    int xcd_group = 32;                 // logical blocks per XCD deal (OAI_XCD_GROUP; 0 = launch order)
+    bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (OAI_SRES_RING=1)
     int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (OAI_SRES_MREP=2|4; 2 runs three workgroups per CU: -2 % on 32 border tiles, +0.5 % on the whole volume)
     bool sres = false;                  // fp16x3 runs split-resident (activations stored as fp16 term pairs, unet_sres.h)
     int n_classes = 0;
@@ -286,7 +288,12 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
     a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? h->sres_mrep : 2) : MREP);
     a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
     a.nbx = cdiv(box.hi[2] - box.lo[2], WX * RX);
-    const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    if (KC == 8 && h->sres && h->xcd_group > 0) {          // XCD-aware dealing of the logical block list (xcd_block_id)
+        a.nblocks = (int)grid; a.xcd_group = h->xcd_group;
+        const unsigned q = 8u * (unsigned)h->xcd_group;
+        grid = (grid + q - 1) / q * q;
+    }
     oai_unet* hm = const_cast<oai_unet*>(h);
     if (h->profile) {
         if (hm->ev_used + 2 > hm->ev_pool.size()) {
@@ -300,6 +307,7 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
     }
     if (KC == 8 && h->sres) {
         if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
+        else if (h->sres_ring) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else conv3_igemm_sres<2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
     }
     else if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
@@ -641,6 +649,11 @@ int oai_unet_set_precision(oai_unet* h, int mode) {
     h->sres = mode == OAI_PREC_FP16X3 && !(sres_env && atoi(sres_env) == 0);
     const char* mrep_env = getenv("OAI_SRES_MREP");
     h->sres_mrep = mrep_env && atoi(mrep_env) == 2 ? 2 : 4;
+    const char* xg_env = getenv("OAI_XCD_GROUP");
+    h->xcd_group = xg_env ? atoi(xg_env) : 32;
+    const char* ring_env = getenv("OAI_SRES_RING");
+    h->sres_ring = ring_env && atoi(ring_env) == 1;
+    if (h->sres_ring) h->sres_mrep = 2;
     return OAI_OK;
 }
 

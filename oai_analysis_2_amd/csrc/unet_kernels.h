@@ -52,6 +52,7 @@ struct ConvArgs {
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
     int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
     int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
+    int nblocks = 0, xcd_group = 0;          // split-resident kernel: true workgroup count and the XCD dealing granularity (see xcd_block_id)
     // split-resident kernel only: dc0 (1x1x1 conv) + sigmoid / threshold + centre crop fused into dc1's epilogue.  When head_w is
     // set the layer's own output is NOT written; every block voxel inside head_boxes[tile] goes to the kept-centre blocks instead.
     const float* head_w = nullptr;           // [ncls][Cout]
@@ -61,6 +62,17 @@ struct ConvArgs {
     int head_ncls = 0, head_mode = 0;        // out_mode of oai_segment_tiles: 0 probability, 1 mask, 2 logit
     int head_k[3] = {0, 0, 0}, head_e[3] = {0, 0, 0};   // origin (in tile coordinates) and extent of a kept-centre block
 };
+
+// Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.  In launch order the cout blocks of one
+// spatial block and its x neighbours -- which read the same halo -- land on eight different L2s.  Re-deal in groups: XCD k
+// takes the logical blocks [(8 i + k) G, (8 i + k + 1) G) for i = 0, 1, ...: neighbours share an L2, and the groups are small
+// enough that the XCDs finish together (whole eighths of the grid were 5 % slower: border tiles are trimmed).  The launch grid
+// is rounded up to a multiple of 8 G; returns -1 for the padding.
+__device__ __forceinline__ int xcd_block_id(int nblocks, int G) {
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const int id = ((j / G) * 8 + xcd) * G + j % G;
+    return id < nblocks ? id : -1;
+}
 
 // intersection of the launch box with the tile's own box; false if the block [o, o+t) misses it entirely
 __device__ __forceinline__ bool tile_box(const int* boxes, int tile, const int (&llo)[3], const int (&lhi)[3],

@@ -1,6 +1,6 @@
 // Split-resident fp16x3 path: activations live in HBM already split into two fp16 terms.
 //
-// Format S of a C-channel tensor:  [tile][z][y][x][C/16 chunks][2 terms][16 channels] fp16  = 4 bytes per element, the same
+// Format S of a C-channel tensor:  [tile][C/16 chunks][z][y][x][2 terms][16 channels] fp16  = 4 bytes per element, the same
 // footprint as fp32, so every buffer of the fp32 path is reused as is.  x = t0 + t1 with t0 = fp16(x), t1 = fp16(x - t0)
 // (22 mantissa bits).  A (voxel, chunk) "record" is 64 contiguous bytes = four 16-byte "slots" (term, channel half) = exactly
 // the four MFMA A-operand fragments v_mfma_f32_32x32x16_f16 wants for that voxel and k-chunk.
@@ -35,11 +35,18 @@ __device__ __forceinline__ float join2_f16(unsigned short hi, unsigned short lo)
     return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
 }
 
+// byte offset of the 64-byte record (tile, chunk, voxel) of a format-S tensor with `nch` chunks and `plane` voxels per tile.
+// Chunk-planar: the records of x-consecutive voxels of one chunk are contiguous, so a halo row is one dense run for the LDS-DMA
+// (with the chunks interleaved per voxel every DMA instruction touched 16 lines instead of 4-5: 7 % of the segmentation).
+__device__ __forceinline__ size_t srec(size_t tile, int nch, size_t plane, int chunk, size_t voxel) {
+    return (((size_t)tile * nch + chunk) * plane + voxel) * 64;
+}
+
 // Store one fp32 value per lane as its two fp16 terms into a format-S row, lanes = consecutive channels `co` of one voxel.
 // Lane pairs (co even, co+1) swap one term with a single DPP move so that every lane issues ONE dword store:
 // even lane -> (hi[co], hi[co+1]) into term 0, odd lane -> (lo[co-1], lo[co]) into term 1.
-__device__ __forceinline__ void store_split_pair(unsigned char* voxel_base /*S record row of the voxel*/, int co, float v, bool pred,
-                                                 int* range_flag) {
+__device__ __forceinline__ void store_split_pair(unsigned char* voxel_base /*record of chunk 0 of the voxel*/, size_t chunk_stride /*plane * 64*/,
+                                                 int co, float v, bool pred, int* range_flag) {
     if (pred && !(fabsf(v) <= 65504.0f)) atomicOr(range_flag, 1);            // fp16 cannot hold it: report, never silently inf
     unsigned lo;
     const unsigned hi = split2_f16(v, lo);
@@ -48,7 +55,7 @@ __device__ __forceinline__ void store_split_pair(unsigned char* voxel_base /*S r
     const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1 /*quad_perm 1,0,3,2*/, 0xF, 0xF, true);
     const unsigned word = odd ? (recv | (lo << 16)) : (hi | (recv << 16));
     if (pred)
-        *reinterpret_cast<unsigned*>(voxel_base + (co >> 4) * 64 + (odd ? 32 : 0) + ((co & 15) >> 1) * 4) = word;
+        *reinterpret_cast<unsigned*>(voxel_base + (co >> 4) * chunk_stride + (odd ? 32 : 0) + ((co & 15) >> 1) * 4) = word;
 }
 
 // Epilogue form of the split: a lane holds ONE channel of two voxels A, B (two C/D rows); its partner lane (lane ^ 1) holds the
@@ -84,8 +91,9 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
         u16x4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { unsigned l; hi[j] = (unsigned short)split2_f16(x[j], l); lo[j] = (unsigned short)l; }
-        *reinterpret_cast<u16x4*>(out + rec * 64 + q * 8) = hi;
-        *reinterpret_cast<u16x4*>(out + rec * 64 + 32 + q * 8) = lo;
+        unsigned char* o = out + srec(0, nch, nvox, ch, vox);
+        *reinterpret_cast<u16x4*>(o + q * 8) = hi;
+        *reinterpret_cast<u16x4*>(o + 32 + q * 8) = lo;
     }
 }
 
@@ -94,19 +102,26 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
 // while the other stages), but the halo arrives by LDS-DMA: no staging registers, no staging VALU.
 // MREP = z slices per block = accumulator row blocks per wave: 4 halves the weight-fragment bytes per MFMA (the L1 path
 // moving 4 KiB of B per wave per tap is what bounds the 3-pass kernel), at 128 accumulator VGPRs.
-template <int MREP, int RX, int RY, int WY, int WX>
-__global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
-    static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4), "bad tile shape");
+// RING (MREP = 2 only): the halo lives in a ring of six z-plane slots instead of one 4-plane box.  A chunk's taps run in dz
+// order and touch planes (dz, dz+1), so the planes of chunk c+1 can be DMA'd into the two spare slots and into the slots chunk c
+// frees as it goes -- every plane is requested three dz-phases (~10 us) before its first use, nothing is ever waited for, and
+// the block synchronises once per phase.  Same footprint as the MREP = 4 box (6 x 11.5 KB), two workgroups per CU.
+template <int MREP, int RX, int RY, int WY, int WX, bool RING = false>
+__global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+    static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4) && (!RING || MREP == 2), "bad tile shape");
     constexpr int NREP = 2, TZ = MREP;
     constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2, HZ = TZ + 2;
     constexpr int HVOX = HZ * HY * HX;
     constexpr int PIECES = HVOX * 4;                            // 16-byte slots of the halo buffer
     constexpr int NIT = (PIECES + 255) / 256;                    // LDS-DMA instructions per thread per chunk
-    constexpr int BUF = NIT * 256 * 16;                          // bytes (whole 1-KiB wave writes)
+    constexpr int NITP = (HY * HX * 4 + 255) / 256;              // RING: ... per thread per z plane
+    constexpr int PLB = NITP * 256 * 16;                         // RING: bytes of one plane slot (whole 1-KiB wave writes)
+    constexpr int BUF = RING ? 6 * PLB : NIT * 256 * 16;         // bytes
     __shared__ __attribute__((aligned(16))) unsigned char lds[BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int id = blockIdx.x;
+    int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
+    if (id < 0) return;
     const int cb = id % a.ncb; id /= a.ncb;
     const int bx = id % a.nbx; id /= a.nbx;
     const int by = id % a.nby; id /= a.nby;
@@ -132,8 +147,8 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
 
     const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
     const size_t plane = (size_t)a.D * a.H * a.W;
-    const unsigned char* s0 = reinterpret_cast<const unsigned char*>(a.src0) + (size_t)tile * plane * nch0 * 64;
-    const unsigned char* s1 = reinterpret_cast<const unsigned char*>(a.src1) + (size_t)tile * plane * nch1 * 64;
+    const unsigned char* s0 = reinterpret_cast<const unsigned char*>(a.src0) + srec(tile, nch0, plane, 0, 0);
+    const unsigned char* s1 = reinterpret_cast<const unsigned char*>(a.src1) + srec(tile, nch1, plane, 0, 0);
 
     // ---- staging plan, once per workgroup: for each of this thread's NIT slots, the voxel it belongs to (-1 = outside the
     // tile, i.e. Conv3d's zero padding, or beyond the halo box -> the zero record) and the logical slot it fetches
@@ -150,17 +165,42 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
     auto stage = [&](int ch) {
         const bool first = ch < nch0;
         const unsigned char* sb = first ? s0 : s1;
-        const int nch = first ? nch0 : nch1;
         const int c = first ? ch : ch - nch0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const unsigned char* g = pv[it] >= 0 ? sb + ((size_t)(pv[it] >> 2) * nch + c) * 64 + ((pslot ^ (pv[it] & 3)) << 4)
-                                                 : zero_rec;
+            const unsigned char* g = pv[it] >= 0 ? sb + ((size_t)c * plane + (size_t)(pv[it] >> 2)) * 64 + ((pslot ^ (pv[it] & 3)) << 4) : zero_rec;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds + (it * 256 + wave * 64) * 16), 16, 0, 0);
         }
     };
 
+    // ---- RING staging plan: this thread's NITP pieces of each of the chunk's four z planes
+    int pvr[RING ? 4 : 1][RING ? NITP : 1];
+    if constexpr (RING) {
+#pragma unroll
+        for (int lp = 0; lp < 4; ++lp)
+#pragma unroll
+            for (int it = 0; it < NITP; ++it) {
+                const int r = (it * 256 + tid) >> 2;
+                const int hx = r % HX, hy = r / HX;
+                const int gz = oz0 - 1 + lp, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+                const bool ok = r < HY * HX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                pvr[lp][it] = ok ? ((((gz * a.H + gy) * a.W + gx) << 2) | ((hx >> 2) & 3)) : -1;
+            }
+    }
+    auto issue_plane = [&](int ch, int lp) {              // logical plane lp of chunk ch -> slot (4 ch + lp) mod 6
+        const bool first = ch < nch0;
+        const unsigned char* sb = first ? s0 : s1;
+        const int c = first ? ch : ch - nch0;
+        unsigned char* dst = lds + ((4 * ch + lp) % 6) * PLB + wave * 1024;
+#pragma unroll
+        for (int it = 0; it < (RING ? NITP : 0); ++it) {
+            const int v = pvr[RING ? lp : 0][RING ? it : 0];
+            const unsigned char* g = v >= 0 ? sb + ((size_t)c * plane + (size_t)(v >> 2)) * 64 + (((tid & 3) ^ (v & 3)) << 4) : zero_rec;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(dst + it * 4096), 16, 0, 0);
+        }
+    };
     // ---- A fragments: byte offset of this lane's voxel for tap (0,0,0), and its swizzled slot per dx and term
     const unsigned char* abase = lds + (ly * HX + lx) * 64;
     int sl[3][2];
@@ -189,6 +229,57 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
             for (int m = 0; m < MREP; ++m)
                 dst[k][m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
     };
+    if constexpr (RING) {
+        const int arel = (ly * HX + lx) * 64;                          // this lane's voxel inside a plane, tap (dy, dx) = (0, 0)
+        issue_plane(0, 0); issue_plane(0, 1); issue_plane(0, 2); issue_plane(0, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            int sb[4];
+#pragma unroll
+            for (int lp = 0; lp < 4; ++lp) sb[lp] = ((4 * ch + lp) % 6) * PLB + arel;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+                if (t % 9 == 0) {                                        // a new dz phase
+                    if (t > 0 || ch > 0) {
+                        // every DMA requested in earlier phases is older than the 2*NREP weight loads in flight: it has landed
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        __syncthreads();                                 // ... for everybody; and the slots refilled below are read out
+                    }
+                    if (ch + 1 < nchunks && !(a.dbg & 1)) {
+                        if (dz == 0) { issue_plane(ch + 1, 0); issue_plane(ch + 1, 1); }
+                        else issue_plane(ch + 1, dz + 1);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int m = 0; m < MREP; ++m)
+                        acur[k][m] = *reinterpret_cast<const float4*>(lds + sb[m + dz] + (dy * HX + dx) * 64 + sl[dx][k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
+                if (!(a.dbg & 2)) wp += STEP;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int m = 0; m < MREP; ++m) {
+                        if (m >= m_lo && m < m_hi) {
+#pragma unroll
+                            for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[PA[p]][m], bcur[PB[p]][n], acc[m][n]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
+            }
+        }
+    } else
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                             // every wave is done reading the previous chunk
         if (!(a.dbg & 1) || ch == 0) stage(ch);
@@ -317,7 +408,7 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
                 const int oz = oz0 + vox / (kTX * kTY), oy = oy0 + (vox / kTX) % kTY, ox = ox0 + vox % kTX;
                 const int chunk = cb * 4 + n * 2 + (q >> 2);
                 if (chunk < nco && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1] && ox >= blo[2] && ox < bhi[2])
-                    *reinterpret_cast<float4*>(outb + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * nco * 64 + chunk * 64 + (q & 3) * 16) =
+                    *reinterpret_cast<float4*>(outb + srec(tile, nco, plane, chunk, ((size_t)oz * a.H + oy) * a.W + ox) + (q & 3) * 16) =
                         *reinterpret_cast<const float4*>(lds + sidx * 16);
             }
         }
@@ -337,7 +428,8 @@ __global__ void __launch_bounds__(256, MREP == 2 ? 3 : 2) conv3_igemm_sres(const
                             float v = fmaxf(fmaxf(val(m, r0), val(m, r0 + 1)), fmaxf(val(m, r0 + 8), val(m, r0 + 9)));
                             v = fmaxf(v, fmaxf(fmaxf(val(m + 1, r0), val(m + 1, r0 + 1)), fmaxf(val(m + 1, r0 + 8), val(m + 1, r0 + 9))));
                             const int x = ox0 + 8 * g + 4 * half + 2 * p, y = oy0 + 2 * wy, z = oz0 + m;
-                            store_split_pair(pb + ((((size_t)tile * Dp + z / 2) * Hp + y / 2) * Wp + x / 2) * nco * 64, co, v, cvalid, a.range_flag);
+                            store_split_pair(pb + srec(tile, nco, (size_t)Dp * Hp * Wp, 0, (((size_t)(z / 2)) * Hp + y / 2) * Wp + x / 2), (size_t)Dp * Hp * Wp * 64,
+                                             co, v, cvalid, a.range_flag);
                         }
                     }
             }
@@ -427,7 +519,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         if (v < nvox) {
             const int x = v % rx, y = (v / rx) % ry, z = v / (rx * ry);
             asrc[it] = reinterpret_cast<const unsigned char*>(a.src) +
-                       ((size_t)tile * plane + ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) * nks * 64 + (((p & 3) ^ ((vl >> 2) & 3)) << 4);
+                       srec(tile, nks, plane, 0, ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) + (((p & 3) ^ ((vl >> 2) & 3)) << 4);
         } else asrc[it] = nullptr;
     }
     const int ngroups = (N + 63) / 64;
@@ -439,7 +531,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         unsigned char* base = ulds + st * kStage + wave * 1024;
 #pragma unroll
         for (int it = 0; it < 2; ++it)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[it] ? asrc[it] + ks * 64 : a.zero),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[it] ? asrc[it] + (size_t)ks * plane * 64 : a.zero),
                                              (__attribute__((address_space(3))) void*)(base + it * 4096), 16, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -489,7 +581,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                     for (int n = 0; n < 4; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
         }
     }
-    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + (size_t)tile * 8 * plane * nco * 64;
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + srec(tile, nco, 8 * plane, 0, 0);      // chunk c of output voxel v at + (c * 8 plane + v) * 64
     if (a.Cout % 16 == 0) {
         // ---- epilogue through LDS, one 64-voxel half (m) at a time: records [voxel 64][16 column chunks][64 B], copied out
         // 16 B per lane: every store instruction writes whole 64-byte records, 1 KiB per wave
@@ -499,7 +591,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         const bool qok = cg < N;
         const int par = qok ? cg / a.Cout : 0, cchunk = qok ? (cg - par * a.Cout) >> 4 : 0;
         const unsigned poff = (unsigned)(((par >> 2) * Ho + ((par >> 1) & 1)) * Wo + (par & 1));
-        const size_t inrow = (size_t)cchunk * 64 + (q & 3) * 16;
+        const size_t inrow = (size_t)cchunk * 8 * plane * 64 + (q & 3) * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
@@ -541,7 +633,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                 const int vl = it * 4 + (tid >> 6);                          // image row: block voxel (vl >> 5) * 64 + m * 32 + (vl & 31)
                 const unsigned e = vtab[(vl >> 5) * 64 + m * 32 + (vl & 31)];
                 if (qok && e != ~0u && !(a.dbg & 64))
-                    *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * nco * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
+                    *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
             }
         }
         if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);
@@ -564,7 +656,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                 float val = acc[m][n][r] * sc + sh;
                 if (a.relu) val = fmaxf(val, 0.0f);
                 // lanes of a pair (co even/odd) share parity and voxel because Cout is even and 32 | lane groups
-                store_split_pair(outb + (size_t)(e == ~0u ? 0 : e + poff) * nco * 64, co, val, cok && e != ~0u, a.range_flag);
+                store_split_pair(outb + (size_t)(e == ~0u ? 0 : e + poff) * 64, 8 * plane * 64, co, val, cok && e != ~0u, a.range_flag);
             }
     }
 }
@@ -642,9 +734,9 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
     const size_t v = ((size_t)z * s.th + y) * s.tw + x;
 #pragma unroll
     for (int vv = 0; vv < 2; ++vv) {
-        unsigned char* o = out + ((size_t)local_tile * plane + v + vv) * NCH * 64;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
+        for (int ch = 0; ch < NCH; ++ch) {
+            unsigned char* o = out + srec(local_tile, NCH, plane, ch, v + vv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u16x4 hi, lo;
@@ -658,9 +750,10 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
                     hi[j] = (unsigned short)split2_f16(r, l);
                     lo[j] = (unsigned short)l;
                 }
-                *reinterpret_cast<u16x4*>(o + ch * 64 + q * 8) = hi;
-                *reinterpret_cast<u16x4*>(o + ch * 64 + 32 + q * 8) = lo;
+                *reinterpret_cast<u16x4*>(o + q * 8) = hi;
+                *reinterpret_cast<u16x4*>(o + 32 + q * 8) = lo;
             }
+        }
     }
 }
 
@@ -680,7 +773,7 @@ __global__ void __launch_bounds__(256) maxpool2_sres_kernel(const unsigned char*
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const unsigned char* p = in + ((((tile * D + 2 * z + (k >> 2)) * H + 2 * y + ((k >> 1) & 1)) * W + 2 * x + (k & 1)) * (size_t)nch + ch) * 64;
+            const unsigned char* p = in + srec(tile, nch, (size_t)D * H * W, ch, (((size_t)(2 * z + (k >> 2))) * H + 2 * y + ((k >> 1) & 1)) * W + 2 * x + (k & 1));
             const u16x4 hi = *reinterpret_cast<const u16x4*>(p + q * 8), lo = *reinterpret_cast<const u16x4*>(p + 32 + q * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], join2_f16(hi[j], lo[j]));
@@ -688,8 +781,9 @@ __global__ void __launch_bounds__(256) maxpool2_sres_kernel(const unsigned char*
         u16x4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { unsigned l; hi[j] = (unsigned short)split2_f16(m[j], l); lo[j] = (unsigned short)l; }
-        *reinterpret_cast<u16x4*>(out + rec * 64 + q * 8) = hi;
-        *reinterpret_cast<u16x4*>(out + rec * 64 + 32 + q * 8) = lo;
+        unsigned char* o = out + srec(tile, nch, (size_t)Do * Ho * Wo, ch, ((size_t)z * Ho + y) * Wo + x);
+        *reinterpret_cast<u16x4*>(o + q * 8) = hi;
+        *reinterpret_cast<u16x4*>(o + 32 + q * 8) = lo;
     }
 }
 
@@ -709,12 +803,13 @@ __global__ void __launch_bounds__(256) head_sres_kernel(const unsigned char* __r
         if (z < b[0] || z >= b[3] || y < b[1] || y >= b[4] || x < b[2] || x >= b[5]) return;
     }
     const int nch = (Cin + 15) / 16;
-    const unsigned char* p = in + ((((size_t)tile * D + z) * H + y) * (size_t)W + x) * nch * 64;
+    const size_t hplane = (size_t)D * H * W;
+    const unsigned char* p = in + srec(tile, nch, hplane, 0, ((size_t)z * H + y) * W + x);
     float acc[4] = {0, 0, 0, 0};
     for (int ch = 0; ch < nch; ++ch)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u16x4 hi = *reinterpret_cast<const u16x4*>(p + ch * 64 + q * 8), lo = *reinterpret_cast<const u16x4*>(p + ch * 64 + 32 + q * 8);
+            const u16x4 hi = *reinterpret_cast<const u16x4*>(p + ch * hplane * 64 + q * 8), lo = *reinterpret_cast<const u16x4*>(p + ch * hplane * 64 + 32 + q * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = ch * 16 + 4 * q + j;
