@@ -203,3 +203,30 @@ def test_fp16x3_reports_activations_outside_fp16_range():
     eng2.set_precision("f32")
     ref = oseg.unet_forward(x.cpu(), big).numpy()
     assert _rel(eng2.forward_tiles(x).cpu().numpy(), ref) < REL                        # the exact mode is unaffected
+
+
+@pytest.mark.parametrize("env", [{"OAI_SRES_MREP": "2"}, {"OAI_SRES_RING": "1"}, {"OAI_XCD_GROUP": "0"}, {"OAI_XCD_GROUP": "7"}, {"OAI_SRES": "0"}])
+def test_split_fp16_kernel_variants_agree(golden_dir, env, monkeypatch):
+    """The tuning variants of the default path (2 z slices per block, the six-slot plane ring, other XCD dealings, fp32-resident
+    activations) accumulate in the same k order: identical stitched maps, and the golden tolerance of the default."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z = np.load(os.path.join(golden_dir, "segment_small.npz"))
+    vol = torch.from_numpy(make_volume(int(z["volume_seed"]), (24, 72, 72))).cuda()
+    patch, ovl = tuple(int(v) for v in z["patch"]), tuple(int(v) for v in z["overlap"])
+    tile_zyx, ovl_zyx, crop_zyx = patch[::-1], ovl[::-1], (ovl[2], ovl[0], ovl[1])
+    sd = make_unet_state_dict(seed=int(z["weight_seed"]))
+
+    def run():
+        eng = UNetEngine(sd, precision="fp16x3")                  # the variant switches are read when the precision is set
+        return eng.stitch(eng.segment_tiles(vol, tile_zyx, ovl_zyx, out_mode=0, batch=9, crop_zyx=crop_zyx), vol.shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
+
+    base = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    if "OAI_SRES" in env:                                          # other activation format: same arithmetic, other rounding points
+        assert np.abs(got - base).max() < 1e-5
+    else:
+        assert np.array_equal(got, base)
+    budget = 12.0 * vol.numel() / 23592960
+    assert np.abs(got[0].astype(np.float64) - z["fc_prob"]).sum() < budget
