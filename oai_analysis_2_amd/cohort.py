@@ -17,18 +17,47 @@ from .pipeline import VolumePipeline, VolumeResult
 
 
 class CohortRunner:
+    """Three things overlap per volume: the compute of volume i (main stream), the host staging + H2D of volume i+1 and the D2H
+    of volume i-1's results (copy stream, persistent pinned buffers).  The host never blocks before the next compute is queued."""
+
     def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False):
         self.pipe = pipeline
         self.keep_on_device = keep_on_device
         self.copy_stream = torch.cuda.Stream(device=pipeline.unet.device)
+        self._pin_in: List[Optional[torch.Tensor]] = [None, None]       # double-buffered pinned upload staging
+        self._pin_ev: List[Optional[torch.cuda.Event]] = [None, None]  # H2D out of each staging buffer has finished
+        self._pin_out: dict = {}
 
-    def _upload(self, img: Image) -> Tuple[torch.Tensor, torch.cuda.Event]:
-        host = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32)).pin_memory()
+    def _upload(self, img: Image, slot: int) -> Tuple[torch.Tensor, torch.cuda.Event]:
+        src = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32))
+        buf = self._pin_in[slot]
+        if buf is None or buf.shape != src.shape:
+            buf = self._pin_in[slot] = torch.empty(src.shape, dtype=torch.float32).pin_memory()
+        if self._pin_ev[slot] is not None:
+            self._pin_ev[slot].synchronize()                              # the previous upload out of this buffer is done
+        buf.copy_(src)                                                    # host memcpy into page-locked memory (no re-pinning per volume)
         with torch.cuda.stream(self.copy_stream):
-            dev = host.to(self.pipe.unet.device, non_blocking=True)
+            dev = buf.to(self.pipe.unet.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        self._pin_ev[slot] = ev
         return dev, ev
+
+    def _download(self, res: VolumeResult, done: torch.cuda.Event) -> VolumeResult:
+        """D2H of one volume's results on the copy stream (after `done`), through reusable pinned buffers."""
+        self.copy_stream.wait_event(done)
+        outs = []
+        with torch.cuda.stream(self.copy_stream):
+            for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
+                t = getattr(res, name)
+                key = (name, tuple(t.shape), t.dtype)
+                if key not in self._pin_out:
+                    self._pin_out[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                self._pin_out[key].copy_(t, non_blocking=True)
+                t.record_stream(self.copy_stream)
+                outs.append(self._pin_out[key])
+        self.copy_stream.synchronize()
+        return VolumeResult(*(o.clone() for o in outs))                  # the pinned buffers are reused by the next volume
 
     def run(self, images: Sequence, rank: int = 0, world: int = 1) -> Iterator[Tuple[int, VolumeResult]]:
         """Yield (index, result) for the volumes this rank owns (index % world == rank), in order."""
@@ -36,13 +65,24 @@ class CohortRunner:
         if not mine:
             return
         imgs = {i: as_image(images[i]) for i in mine}
-        nxt = self._upload(imgs[mine[0]])
+        nxt = self._upload(imgs[mine[0]], 0)
+        pending = None                                                    # (index, device results, completion event) of the previous volume
         for k, i in enumerate(mine):
             dev, ev = nxt
-            if k + 1 < len(mine):
-                nxt = self._upload(imgs[mine[k + 1]])           # overlaps with this volume's compute
             torch.cuda.current_stream().wait_event(ev)
-            res = self.pipe.run(dev, imgs[i])
-            if not self.keep_on_device:
-                res = VolumeResult(*(t.cpu() for t in (res.fc, res.tc, res.phi, res.fc_atlas, res.tc_atlas)))
-            yield i, res
+            dev.record_stream(torch.cuda.current_stream())                # allocated on the copy stream, read by the compute stream
+            res = self.pipe.run(dev, imgs[i])                             # queued, not waited for
+            done = torch.cuda.Event()
+            done.record()
+            if k + 1 < len(mine):
+                nxt = self._upload(imgs[mine[k + 1]], (k + 1) & 1)        # host staging + H2D behind this volume's compute
+            if pending is not None:
+                pi, pres, pdone = pending
+                yield pi, (pres if self.keep_on_device else self._download(pres, pdone))
+            pending = (i, res, done)
+        pi, pres, pdone = pending
+        if self.keep_on_device:
+            pdone.synchronize()
+            yield pi, pres
+        else:
+            yield pi, self._download(pres, pdone)
