@@ -130,3 +130,12 @@ def make_icon_state_dict(seed: int = 0, last_scale: float = 0.3) -> "OrderedDict
         for k, v in make_icon_unet_state_dict(seed * 3 + i, last_scale=last_scale).items():
             out[prefix + k] = v
     return out
+
+
+def identity_map(shape_dhw) -> np.ndarray:
+    """[3,D,H,W] float32 map in ICON's [0,1] units: channel d = float32(index_d * (1 / (n_d - 1))) (the package's identity_map)."""
+    D, H, W = (int(v) for v in shape_dhw)
+    g = np.mgrid[0:D, 0:H, 0:W].astype(np.float64)
+    for d, n in enumerate((D, H, W)):
+        g[d] *= 1.0 / (n - 1)
+    return g.astype(np.float32)

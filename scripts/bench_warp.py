@@ -7,8 +7,7 @@ import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oai_analysis_2_amd import ops
-from oai_analysis_2_amd.synth import make_smooth_field, make_volume
-from oracle import icon as oicon
+from oai_analysis_2_amd.synth import identity_map, make_smooth_field, make_volume
 
 N = int(os.environ.get("N", "160"))
 shape = (N, N, N)
@@ -16,7 +15,7 @@ V = N ** 3
 img = torch.from_numpy(make_volume(1, shape))[None].cuda()
 d_full = torch.from_numpy(make_smooth_field(2, shape, 0.02)).cuda()
 d_half = torch.from_numpy(make_smooth_field(3, (N // 2,) * 3, 0.02)).cuda()
-coords = (oicon.identity_map(shape)[0] + torch.from_numpy(make_smooth_field(4, shape, 0.03))).cuda().contiguous()
+coords = (torch.from_numpy(identity_map(shape)) + torch.from_numpy(make_smooth_field(4, shape, 0.03))).cuda().contiguous()
 
 def timeit(fn, iters=50):
     for _ in range(5): fn()
