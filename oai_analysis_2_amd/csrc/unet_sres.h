@@ -219,8 +219,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     wp += STEP;
 
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-    constexpr bool APF = false;     // A-fragment register prefetch: no gain measured (MREP 2), and it costs the third workgroup per CU
-    float4 acur[2][MREP], anext[2][MREP];
+    float4 acur[2][MREP];           // (a register prefetch of the next tap's A fragments was measured: no gain, and it costs MREP 2 its third workgroup per CU)
     auto load_a = [&](float4 (&dst)[2][MREP], int t) {
         const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
 #pragma unroll
@@ -285,13 +284,9 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         if (!(a.dbg & 1) || ch == 0) stage(ch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
         __syncthreads();                                             // ... and everybody else's
-        if constexpr (APF) load_a(acur, 0);
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
-            // A fragments: with registers to spare (MREP = 2) the NEXT tap's are fetched behind this tap's MFMAs, so that no
-            // tap starts by waiting an LDS round trip; otherwise they are read at the top of the tap (counted lgkmcnt waits)
-            if constexpr (!APF) load_a(acur, t);
-            else if (t + 1 < 27) load_a(anext, t + 1);
+            load_a(acur, t);                                         // read at the top of the tap (counted lgkmcnt waits)
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -312,14 +307,6 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
-            if constexpr (APF) {
-                if (t + 1 < 27) {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int m = 0; m < MREP; ++m) acur[k][m] = anext[k][m];
-                }
-            }
         }
     }
 
