@@ -29,6 +29,20 @@ int edge_of(int c0, int c1) {
     return 2 * 4 + x + 2 * y;
 }
 
+// do two cube edges lie on a common cube face?  edge = axis * 4 + j, j's two bits = the coordinates along the other two axes
+bool share_face(int e1, int e2) {
+    auto faces = [](int e, int (&f)[2]) {
+        const int axis = e >> 2, j = e & 3;
+        const int o0 = axis == 0 ? 1 : 0, o1 = axis == 2 ? 1 : 2;
+        f[0] = o0 * 2 + (j & 1);
+        f[1] = o1 * 2 + (j >> 1);
+    };
+    int a[2], b[2];
+    faces(e1, a);
+    faces(e2, b);
+    return a[0] == b[0] || a[0] == b[1] || a[1] == b[0] || a[1] == b[1];
+}
+
 struct Tables {
     signed char tri[256][16];
     unsigned char ntri[256];
@@ -65,10 +79,18 @@ const Tables& host_tables() {
                 if (nxt[start] < 0 || seen[start]) continue;
                 int loop[12], len = 0;
                 for (int e = start; !seen[e]; e = nxt[e]) { seen[e] = true; loop[len++] = e; }
+                // fan apex: the first rotation with no diagonal lying in a cube face (the neighbouring cube could draw the same
+                // diagonal on the shared face: four triangles on one edge)
+                int best = 0, best_bad = 1 << 30;
+                for (int r = 0; r < len; ++r) {
+                    int bad = 0;
+                    for (int i = 2; i < len - 1; ++i) bad += share_face(loop[r], loop[(r + i) % len]) ? 1 : 0;
+                    if (bad < best_bad) { best_bad = bad; best = r; }
+                }
                 for (int i = 1; i + 1 < len; ++i) {
-                    t.tri[cs][n++] = (signed char)loop[0];
-                    t.tri[cs][n++] = (signed char)loop[i];
-                    t.tri[cs][n++] = (signed char)loop[i + 1];
+                    t.tri[cs][n++] = (signed char)loop[best];
+                    t.tri[cs][n++] = (signed char)loop[(best + i) % len];
+                    t.tri[cs][n++] = (signed char)loop[(best + i + 1) % len];
                 }
             }
             t.ntri[cs] = (unsigned char)(n / 3);

@@ -8,7 +8,8 @@ tests assert nothing on meshes, so this file restates the published algorithms:
 * marching cubes (Lorensen & Cline) with a case table GENERATED from first principles (``mc_table``): on every cube face the
   iso-line segments are fixed by the face's corner signs alone (ambiguous faces always isolate the inside corners), so two
   cubes sharing a face agree and the surface is watertight; the segments chain into closed loops, each fan-triangulated from
-  its lowest edge.  The vertex SET equals that of any marching-cubes variant (one vertex per sign-changing grid edge, linear
+  the first loop vertex (lowest edge first) that draws no diagonal inside a cube face, so the surface is also an oriented
+  2-manifold (every directed edge once).  The vertex SET equals that of any marching-cubes variant (one vertex per sign-changing grid edge, linear
   interpolation); the triangulation differs from Lewiner's in ambiguous cells.
 * Laplacian smoothing x <- x + f * (mean of edge neighbours - x), Jacobi sweeps (vtk sweeps in place, Gauss-Seidel order).
 * unsigned distance from points to a triangle soup, exact closest point on each triangle (Ericson, Real-Time Collision
@@ -61,6 +62,17 @@ def edge_corners(e: int) -> Tuple[int, int]:
     return lo, lo | (1 << axis)
 
 
+def _edge_faces(e: int):
+    """the two cube faces (axis, side) that contain cube edge e"""
+    axis, j = divmod(e, 4)
+    others = [ax for ax in range(3) if ax != axis]
+    return {(others[0], j & 1), (others[1], j >> 1)}
+
+
+def _share_face(e1: int, e2: int) -> bool:
+    return bool(_edge_faces(e1) & _edge_faces(e2))
+
+
 @lru_cache(maxsize=None)
 def mc_table() -> np.ndarray:
     """[256][16] int8: up to 5 triangles as edge-id triples, -1 terminated.  Bit c of the case index = corner c inside."""
@@ -95,6 +107,12 @@ def mc_table() -> np.ndarray:
                 loop.append(e)
                 e = nxt[e]
             assert e == start and len(loop) >= 3
+            # fan apex: the first rotation of the loop with no diagonal lying IN a cube face -- the neighbouring cube could
+            # draw the same diagonal on the shared face, and the edge would carry four triangles (non-manifold)
+            n = len(loop)
+            rot = min(range(n), key=lambda r: (sum(_share_face(loop[r], loop[(r + i) % n]) for i in range(2, n - 1)), r))
+            assert sum(_share_face(loop[rot], loop[(rot + i) % n]) for i in range(2, n - 1)) == 0
+            loop = loop[rot:] + loop[:rot]
             for i in range(1, len(loop) - 1):
                 tris.append((loop[0], loop[i], loop[i + 1]))
         assert len(tris) <= 5, (case, tris)

@@ -58,3 +58,16 @@ def test_oracle_smoothing_and_distance():
     r = np.linalg.norm(v[:40] - c, axis=1)
     assert np.all(d <= 0.25 * r + 1e-6) and np.all(d > 0.15 * r)
     assert np.allclose(om.distance_to_mesh(v[:10], v, f), 0, atol=1e-5)
+
+
+def test_oracle_surface_of_noise_is_an_oriented_manifold():
+    """every one of the 256 cases, ambiguous faces included: each directed edge exactly once, its reverse present unless the
+    surface is cut by the volume border (no fan diagonal lies in a cube face, so neighbouring cubes never draw the same edge)"""
+    vol = np.random.default_rng(0).random((14, 15, 16)).astype(np.float32)
+    v, f = om.marching_cubes(vol, 0.5)
+    assert len(np.unique(om.mc_table()[:, 0])) > 1 and len(f) > 5000
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]).astype(np.int64)
+    key, rkey = e[:, 0] * len(v) + e[:, 1], e[:, 1] * len(v) + e[:, 0]
+    assert len(np.unique(key)) == len(key)
+    interior = np.all((v[e] > 0.0) & (v[e] < np.array(vol.shape[::-1], np.float32) - 1.0), axis=(1, 2))
+    assert np.isin(rkey[interior], key).all()
