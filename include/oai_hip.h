@@ -164,7 +164,8 @@ int oai_segment_tiles(oai_unet* h, const float* vol_dev, int D, int H, int W,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Partition.assemble (non-vote branch): scatter centre blocks of ALL tiles into
- * maps[n_classes][D][H][W], trim to the image, zero the outer frame of crop_zyx voxels. */
+ * maps[n_classes][D][H][W], trim to the image, zero the outer frame of crop_zyx voxels.  A crop with a zero component
+ * gives an all-zero map, as the reference's `[c:-c]` slicing does (image_transforms.py:509-513). */
 int oai_stitch_blocks(const float* blocks_dev, int n_classes, int D, int H, int W,
                       const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
                       float* maps_dev, void* stream);

@@ -914,6 +914,12 @@ int oai_stitch_blocks(const float* blocks, int ncls, int D, int H, int W, const 
         grid[i] = (size[i] + eff[i] - 1) / eff[i];
     }
     const size_t total = (size_t)ncls * D * H * W;
+    if (crop && (crop[0] == 0 || crop[1] == 0 || crop[2] == 0)) {
+        // image_transforms.py:509-513 copies [c:-c] per axis into a zero array; with c == 0 the numpy slice 0:-0 is EMPTY, so a
+        // crop_size with a zero component (an overlap of 0 on some axis) yields an all-zero map in the reference.  Reproduced.
+        OAI_CHECK_HIP(hipMemsetAsync(maps, 0, total * sizeof(float), (hipStream_t)stream));
+        return OAI_OK;
+    }
     size_t nblk = (total + 255) / 256;
     if (nblk > 256 * 32) nblk = 256 * 32;
     stitch_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(blocks, ncls, D, H, W, eff[0], eff[1], eff[2], grid[1], grid[2],

@@ -134,14 +134,17 @@ def test_bf16x3_prob_maps_within_the_north_star_tolerance(golden_dir):
 
 @pytest.mark.parametrize("shape,patch,ovl", [((21, 45, 38), (32, 32, 16), (8, 8, 4)),      # ragged: hi padding != overlap
                                              ((9, 20, 70), (32, 16, 8), (4, 2, 1)),        # reflect pad wider than the tile centre
-                                             ((16, 32, 32), (32, 32, 16), (8, 8, 4))])     # exactly one tile's centre... plus frame
-def test_segment_ragged_volumes_vs_oracle(shape, patch, ovl):
+                                             ((16, 32, 32), (32, 32, 16), (8, 8, 4)),      # exactly one tile's centre... plus frame
+                                             ((30, 72, 68), (32, 32, 16), (6, 5, 1)),      # x / y overlaps differ: crop_size[0] lands on y (:511-512)
+                                             ((13, 57, 52), (32, 32, 8), (5, 1, 0))])      # an overlap of 0: numpy's [0:-0] is empty -> all-zero maps
+@pytest.mark.parametrize("precision", ["f32", "fp16x3"])
+def test_segment_ragged_volumes_vs_oracle(shape, patch, ovl, precision):
     """Partition edge cases of image_transforms.py:407-415 on the gather-fused path (no golden: oracle is pinned)."""
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
     sd = make_unet_state_dict(seed=7, width_div=4)
     vol = make_volume(3, shape)
     fc_ref, tc_ref = oseg.segment(vol, sd, patch, ovl, output_prob=True)
-    eng = UNetEngine(sd)
+    eng = UNetEngine(sd, precision=precision)
     tile_zyx, ovl_zyx, crop_zyx = patch[::-1], ovl[::-1], (ovl[2], ovl[0], ovl[1])
     blocks = eng.segment_tiles(torch.from_numpy(vol).cuda(), tile_zyx, ovl_zyx, out_mode=0, batch=5)
     maps = eng.stitch(blocks, shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
@@ -150,8 +153,11 @@ def test_segment_ragged_volumes_vs_oracle(shape, patch, ovl):
     blocks2 = eng.segment_tiles(torch.from_numpy(vol).cuda(), tile_zyx, ovl_zyx, out_mode=0, batch=5, crop_zyx=crop_zyx)
     maps2 = eng.stitch(blocks2, shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
     assert np.array_equal(maps2, maps)
-    assert eng.volume_flops(shape, tile_zyx, ovl_zyx, crop_zyx) < eng.volume_flops(shape, tile_zyx, ovl_zyx, None)
-    assert maps[0][:crop_zyx[0]].max() == 0 and maps[0][:, :, -crop_zyx[2]:].max() == 0      # the zeroed frame
+    if min(crop_zyx) > 0:
+        assert eng.volume_flops(shape, tile_zyx, ovl_zyx, crop_zyx) < eng.volume_flops(shape, tile_zyx, ovl_zyx, None)
+        assert maps[0][:crop_zyx[0]].max() == 0 and maps[0][:, :, -crop_zyx[2]:].max() == 0      # the zeroed frame
+    else:
+        assert fc_ref.max() == 0 and maps.max() == 0                                                # the reference's degenerate case, reproduced
 
 
 def test_bad_arguments_raise():
