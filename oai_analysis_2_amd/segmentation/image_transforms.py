@@ -54,3 +54,35 @@ class Partition(object):
         sample = dict(sample)
         sample["image"] = tiles
         return sample
+
+    def assemble(self, tiles, is_vote=False, if_itk=True, crop_size=None, data_type=None):
+        """Partition.assemble (image_transforms.py:457-519), non-vote branch: kept tile centres -> image, trimmed to the image
+        size, the outer frame of ``crop_size`` zeroed (``crop_size`` indexed like the reference: [2] is z, [0] lands on numpy
+        axis 1, [1] on axis 2; a zero component zeroes everything, :509-513).  Runs on the device (oai_stitch_blocks);
+        returns float64 like the reference unless ``data_type`` is given."""
+        if is_vote:
+            raise NotImplementedError("is_vote=True (label voting over overlaps) is not on the prediction path (segmenter.py:126-129)")
+        from .. import _lib
+        lib = _lib.load()
+        t = torch.as_tensor(np.asarray(tiles) if not isinstance(tiles, torch.Tensor) else tiles).to(torch.float32)
+        if t.dim() == 5:
+            t = t[:, 0]
+        tz, ty, tx = (int(v) for v in self.tile_size)
+        oz, oy, ox = (int(v) for v in self.overlap_size)
+        D, H, W = (int(v) for v in self.image_size)
+        eff, grid, n = tile_grid((D, H, W), (tz, ty, tx), (oz, oy, ox))
+        if t.shape[0] != n or tuple(t.shape[1:]) != (tz, ty, tx):
+            raise ValueError(f"assemble needs {n} tiles of {tz}x{ty}x{tx}, got {tuple(t.shape)}")
+        blocks = t[:, oz:tz - oz, oy:ty - oy, ox:tx - ox].contiguous().cuda()            # [N][ez][ey][ex], one class
+        maps = torch.empty((1, D, H, W), dtype=torch.float32, device=blocks.device)
+        crop = _lib.int3((int(crop_size[2]), int(crop_size[0]), int(crop_size[1]))) if crop_size is not None and len(crop_size) else None
+        with torch.cuda.device(blocks.device):
+            _lib.check(lib.oai_stitch_blocks(blocks.data_ptr(), 1, D, H, W, _lib.int3((tz, ty, tx)), _lib.int3((oz, oy, ox)), crop,
+                                             maps.data_ptr(), torch.cuda.current_stream().cuda_stream), "oai_stitch_blocks")
+        out = maps[0].cpu().numpy().astype(data_type if data_type else np.float64)
+        if if_itk:
+            img = Image(out)
+            if getattr(self, "image", None) is not None:
+                img.CopyInformation(self.image)
+            return img
+        return out

@@ -80,3 +80,22 @@ def test_analysis_object_end_to_end(tmp_path):
     ref = oresample.resample_through_phi(FC.array, disp_ref, img, atlas)
     assert warped.array.shape == atlas.array.shape and warped.array.dtype == np.float64
     assert np.abs(warped.array - ref).max() < 1e-4
+
+
+def test_partition_call_and_assemble_like_the_reference():
+    """Partition used directly (image_transforms.py:388-519): tiles, then assemble with the reference's crop_size indexing."""
+    from oai_analysis_2_amd.segmentation.image_transforms import Partition
+    vol = make_volume(4, (20, 50, 44))
+    patch, ovl = (32, 24, 16), (6, 4, 3)                        # x,y,z ; x / y overlaps differ on purpose
+    part = Partition(patch, ovl)
+    tiles = part({"image": Image(vol, [0.5, 0.5, 1.0]), "name": "v"})["image"]
+    ref_tiles, g = oseg.partition(vol, patch, ovl)
+    assert np.array_equal(tiles.cpu().numpy()[:, 0], ref_tiles[:, 0] if ref_tiles.ndim == 5 else ref_tiles)
+    for crop in (None, ovl, (6, 4, 0)):
+        got = part.assemble(tiles[:, 0].cpu(), if_itk=False, crop_size=crop)
+        ref = oseg.assemble(ref_tiles[:, 0] if ref_tiles.ndim == 5 else ref_tiles, g, crop_size_xyz=crop)
+        assert got.dtype == np.float64 and np.array_equal(got, ref.astype(np.float64))
+    img = part.assemble(tiles, if_itk=True, crop_size=ovl)
+    assert isinstance(img, Image) and np.allclose(img.spacing, [0.5, 0.5, 1.0])
+    with pytest.raises(NotImplementedError):
+        part.assemble(tiles, is_vote=True)
