@@ -724,22 +724,21 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             unsigned char* o = out + srec(local_tile, NCH, plane, ch, v + vv);
+            u16x8 hi[2], lo[2];                                  // the whole 64-byte record in registers: four 16-byte stores
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u16x4 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = ch * 16 + 4 * q + j;
-                    float r = 0.0f;
-                    if (c < COUT) { r = acc[vv][c < COUT ? c : 0] * scale[c < COUT ? c : 0] + shift[c < COUT ? c : 0]; if (relu) r = fmaxf(r, 0.0f); }
-                    if (!(fabsf(r) <= 65504.0f)) atomicOr(range_flag, 1);
-                    unsigned l;
-                    hi[j] = (unsigned short)split2_f16(r, l);
-                    lo[j] = (unsigned short)l;
-                }
-                *reinterpret_cast<u16x4*>(o + q * 8) = hi;
-                *reinterpret_cast<u16x4*>(o + 32 + q * 8) = lo;
+            for (int j = 0; j < 16; ++j) {
+                const int c = ch * 16 + j;
+                float r = 0.0f;
+                if (c < COUT) { r = acc[vv][c < COUT ? c : 0] * scale[c < COUT ? c : 0] + shift[c < COUT ? c : 0]; if (relu) r = fmaxf(r, 0.0f); }
+                if (!(fabsf(r) <= 65504.0f)) atomicOr(range_flag, 1);
+                unsigned l;
+                hi[j >> 3][j & 7] = (unsigned short)split2_f16(r, l);
+                lo[j >> 3][j & 7] = (unsigned short)l;
             }
+            *reinterpret_cast<u16x8*>(o) = hi[0];
+            *reinterpret_cast<u16x8*>(o + 16) = hi[1];
+            *reinterpret_cast<u16x8*>(o + 32) = lo[0];
+            *reinterpret_cast<u16x8*>(o + 48) = lo[1];
         }
     }
 }
