@@ -33,3 +33,27 @@ def test_bad_arguments_are_reported_not_crashed():
     assert rc != 0 and b"null" in lib.oai_last_error()
     rc = lib.oai_avgpool2_3d(None, 0, 0, 0, 0, None, None)
     assert rc != 0
+
+
+def test_argument_checks_of_the_later_entry_points():
+    """Bad arguments come back as a non-zero status with a message -- no GPU is touched before the checks."""
+    import ctypes as C
+    lib = _lib.load()
+    nv, nt = C.c_longlong(), C.c_longlong()
+    assert lib.oai_mc_count(None, 8, 8, 8, 0.5, None, 0, C.byref(nv), C.byref(nt), None) != 0 and b"null" in lib.oai_last_error()
+    dummy = (C.c_float * 8)()
+    assert lib.oai_mc_count(dummy, 1, 8, 8, 0.5, dummy, 32, C.byref(nv), C.byref(nt), None) != 0 and b"at least 2" in lib.oai_last_error()
+    assert lib.oai_mc_count(dummy, 8, 8, 8, 0.5, dummy, 32, C.byref(nv), C.byref(nt), None) != 0 and b"workspace" in lib.oai_last_error()
+    assert lib.oai_mc_workspace_bytes(1, 8, 8) == 0 and lib.oai_mc_workspace_bytes(160, 384, 384) > 160 * 384 * 384 * 17
+    assert lib.oai_mesh_smooth(None, 10, None, None, 5, 0.1, None, None, None) != 0
+    assert lib.oai_mesh_point_distance(dummy, 1, dummy, dummy, 0, dummy, None) != 0 and b"triangle" in lib.oai_last_error()
+    gd = (C.c_int * 3)(4, 4, 4)
+    assert lib.oai_mesh_grid_workspace_bytes(gd, 100) > 0 and lib.oai_mesh_grid_workspace_bytes(gd, 0) == 0
+    glo = (C.c_float * 3)(0, 0, 0)
+    assert lib.oai_mesh_point_distance_grid(dummy, 1, dummy, dummy, 4, glo, -1.0, gd, dummy, 1 << 20, dummy, None) != 0
+    assert lib.oai_mesh_point_distance_grid(dummy, 1, dummy, dummy, 4, glo, 1.0, gd, dummy, 16, dummy, None) != 0 and b"workspace" in lib.oai_last_error()
+    t = (C.c_int * 3)(32, 128, 128)
+    o = (C.c_int * 3)(16, 64, 64)                                     # overlap eats the whole tile
+    assert lib.oai_stitch_blocks(dummy, 2, 16, 16, 16, t, o, None, dummy, None) != 0 and b"overlap" in lib.oai_last_error()
+    assert lib.oai_unet_set_precision(None, 3) != 0
+    assert lib.oai_image_normalize(None, 10, 0.1, 99.9, 0.0, 1.0, None, None, None, 0, None) != 0
