@@ -30,7 +30,7 @@ Dominant kernel of the default mode = `conv3_igemm_sres<4, ...>` (split-resident
   History: 77 GB fetched with chunk-interleaved records and launch-order blocks; chunk-planar records (whole 128-B lines per
   DMA) and dealing the logical block list to the XCDs in groups of 32 (halo-sharing neighbours and cout blocks on one L2) brought
   it to {t["fetch_x2_bytes_per_32_tile_pass"]/1e9:.0f} GB -- worth only ~1 % of time: the DMA is asynchronous and the data was coming from the Infinity Cache.
-* value {d["value"]:.2f} volumes/s ({d["ms_per_step"]:.1f} ms per volume: segment + register + 2 resamples); box-to-box spread of the same build: 4.85-5.04
+* value {d["value"]:.2f} volumes/s ({d["ms_per_step"]:.1f} ms per volume: segment + register + 2 resamples); the ICON registration of the same volume runs on a side stream underneath the segmentation; box-to-box spread of this build: 5.03-5.13
 
 `conv3_igemm_f32` (alt precision f32, exact fp32 MFMA): {a["value"]:.2f} volumes/s, {a["roofline"]["achieved"]:.1f} TFLOP/s = {a["roofline"]["frac"]:.3f} of the
 157.3 TFLOP/s fp32 MFMA peak ({a["roofline"]["executed_frac"]:.2f} on the stricter frame-aware FLOP count).
