@@ -172,8 +172,8 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
                       "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
-                      "fp16x3": "fp16x3 (fp32 operands split into 2 fp16 terms = 22 mantissa bits, 3 MFMA passes, fp32 accumulate; "
-                                "fp32 activations in memory)"}[args.precision], "data": "synthetic",
+                      "fp16x3": "fp16x3 (every fp32 value held as 2 fp16 terms = 22 mantissa bits, 3 MFMA passes per product, fp32 accumulate; "
+                                "fp32 in and out of every entry point)"}[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": getattr(unet, "last_batch", args.batch), "parallelism": f"{args.mode} x{world}"},
