@@ -501,7 +501,7 @@ struct UpArgs {
     const int* boxes;                   // optional [tile][6]: the part of the INPUT box this tile needs
     int* range_flag;                    // split-fp16: set when an input is outside fp16's range
     const unsigned char* zero = nullptr; // split-resident kernel: 64 zero bytes, the LDS-DMA source of rows / columns that do not exist
-    int dbg = 0;                        // diagnostic timing switches (OAI_DBG bits 64/128/256; results wrong when set)
+    int dbg = 0;                        // diagnostic timing switches (OAI_DBG bits 64/128/256/512; results wrong when set)
 };
 
 // SPLIT = false: exact fp32 MFMA.  SPLIT = true: split-fp16, 3 passes (see conv3_igemm_bf16s): the A rows are split in

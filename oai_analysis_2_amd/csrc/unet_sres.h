@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
-            if (active) {
+            if (active && !(a.dbg & 512)) {
                 unsigned vmask = 0;                                          // which of this lane's 16 voxel rows are real outputs
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
