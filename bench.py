@@ -141,7 +141,12 @@ def main():
 
     if rank == 0:
         _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
-        my_frac = 1.0 if args.mode == "replicas" else len(range(*tile_range_for_rank(n_tiles, rank, world))) / n_tiles
+        if args.mode == "replicas":
+            my_frac = 1.0
+        else:                                        # rank 0's share of the volume's work under the cost-balanced tile split
+            costs = unet.tile_costs(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX)
+            b, e = tile_range_for_rank(n_tiles, rank, world, costs)
+            my_frac = sum(costs[b:e]) / sum(costs)
         # roofline.achieved uses SURVEY.md 8(d)'s contract figure: 505.4 GFLOP per tile = per-layer trim boxes of App. B.1
         # (the part of it that the 3x3x3 kernel runs).  The kernels additionally skip, per border tile, the part of the
         # kept centre that Partition.assemble zeroes (the 8/16/16 frame): that stricter "frame-aware" count is reported

@@ -182,6 +182,10 @@ double oai_unet_tile_flops(const oai_unet* h, int td, int th, int tw, const int 
  * conv3_only restricts the sum to the layers of the 3x3x3 implicit-GEMM kernel. */
 double oai_unet_volume_flops(const oai_unet* h, int D, int H, int W, const int tile_zyx[3], const int overlap_zyx[3],
                              const int crop_zyx[3], int trimmed, int conv3_only);
+/* FLOPs of every tile of a volume as oai_segment_tiles computes it (border tiles cost less: trimmed kept centres): the weights
+ * for splitting ONE volume's tiles over ranks (the reference's z-major order; oai_analysis_2_amd/parallel.py). */
+int oai_unet_tile_costs(const oai_unet* h, int D, int H, int W, const int tile_zyx[3], const int overlap_zyx[3],
+                        const int crop_zyx[3], double* costs_host, int n_tiles);
 /* Same as oai_unet_tile_flops, restricted to the layers the 3x3x3 implicit-GEMM kernel runs (ec1-ec7, dc8, dc7, dc5, dc4, dc2, dc1). */
 double oai_unet_tile_flops_conv3(const oai_unet* h, int td, int th, int tw, const int overlap_zyx[3], int trimmed);
 

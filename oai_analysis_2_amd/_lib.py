@@ -45,6 +45,7 @@ SIGNATURES = {
     "oai_phi_to_itk_displacement": (_I, [_P, _I, _I, _I, _P, _P]),
     "oai_resample_through_disp": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
                                        _P, _I, _I, _I, _P]),
+    "oai_unet_tile_costs": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),
     "oai_mc_table": (_I, [_P]),
     "oai_mc_workspace_bytes": (_Z, [_I, _I, _I]),
     "oai_mc_count": (_I, [_P, _I, _I, _I, _F, _P, _Z, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _P]),

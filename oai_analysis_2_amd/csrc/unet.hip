@@ -903,6 +903,23 @@ double oai_unet_volume_flops(const oai_unet* h, int D, int H, int W, const int t
     return f;
 }
 
+int oai_unet_tile_costs(const oai_unet* h, int D, int H, int W, const int tile[3], const int overlap[3], const int crop[3],
+                        double* costs_host, int n_tiles) {
+    OAI_CHECK_ARG(h && tile && overlap && costs_host, "oai_unet_tile_costs: null pointer");
+    SegGeom g;
+    if (int rc = seg_geometry(D, H, W, tile, overlap, g)) return rc;
+    OAI_CHECK_ARG(n_tiles == g.ntiles, "oai_unet_tile_costs: the volume has %d tiles, not %d", g.ntiles, n_tiles);
+    Box need[18];
+    const SegParams sp = seg_params(D, H, W, tile, overlap, crop, g, true);
+    for (int t = 0; t < g.ntiles; ++t) {
+        tile_regions(t, sp, need);
+        double f = 0.0;
+        for (int k = 0; k < 18; ++k) f += layer_flops(h, k, need[k]);
+        costs_host[t] = f;
+    }
+    return OAI_OK;
+}
+
 int oai_stitch_blocks(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],
                       const int crop[3], float* maps, void* stream) {
     OAI_CHECK_ARG(blocks && maps && tile && overlap, "oai_stitch_blocks: null pointer");

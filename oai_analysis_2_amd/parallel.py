@@ -15,24 +15,40 @@ with the gloo backend (tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def tile_range_for_rank(n_tiles: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous, balanced split: the first n_tiles % world ranks take one extra tile."""
-    base, extra = divmod(n_tiles, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+def tile_range_for_rank(n_tiles: int, rank: int, world: int, costs: Optional[Sequence[float]] = None) -> Tuple[int, int]:
+    """Contiguous split of the tile list.  Without ``costs``: balanced by count (the first n_tiles % world ranks take one extra
+    tile).  With per-tile ``costs`` (``UNetEngine.tile_costs``: border tiles are cheaper, their kept centre is trimmed): the
+    boundaries are placed where the running cost crosses k / world of the total, so that every rank gets the same WORK; every
+    rank still gets a (possibly empty) contiguous range and the ranges tile [0, n_tiles) in rank order."""
+    if costs is None:
+        base, extra = divmod(n_tiles, world)
+        begin = rank * base + min(rank, extra)
+        return begin, begin + base + (1 if rank < extra else 0)
+    if len(costs) != n_tiles:
+        raise ValueError("one cost per tile")
+    total = float(sum(costs))
+    bounds, acc, t = [0], 0.0, 0
+    for k in range(1, world):
+        target = total * k / world
+        while t < n_tiles and acc + 0.5 * float(costs[t]) <= target:       # a tile goes to the side its midpoint falls on
+            acc += float(costs[t])
+            t += 1
+        bounds.append(t)
+    bounds.append(n_tiles)
+    return bounds[rank], bounds[rank + 1]
 
 
 def volumes_for_rank(n_volumes: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_volumes, world))
 
 
-def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None) -> torch.Tensor:
+def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None, costs: Optional[Sequence[float]] = None) -> torch.Tensor:
     """all_gather the per-rank centre blocks [n_local, C, ez, ey, ex] into [n_tiles, C, ez, ey, ex].
 
     Ranges are contiguous and ordered by rank, so concatenating the gathered pieces is the stitch order.
@@ -42,7 +58,7 @@ def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None) -> torch
     if not dist.is_initialized():
         return local_blocks
     rank = dist.get_rank(group)
-    counts = [tile_range_for_rank(n_tiles, r, world) for r in range(world)]
+    counts = [tile_range_for_rank(n_tiles, r, world, costs) for r in range(world)]
     max_n = max(e - b for b, e in counts)
     tail = local_blocks.shape[1:]
     if counts[rank][1] - counts[rank][0] != local_blocks.shape[0]:
@@ -60,9 +76,10 @@ def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None) -> torch
     return torch.cat(pieces, 0)
 
 
-def segment_tile_sharded(compute_blocks: Callable[[Tuple[int, int]], torch.Tensor], n_tiles: int, group=None) -> torch.Tensor:
-    """Every rank computes its tile range, then all ranks hold all blocks."""
+def segment_tile_sharded(compute_blocks: Callable[[Tuple[int, int]], torch.Tensor], n_tiles: int, group=None,
+                         costs: Optional[Sequence[float]] = None) -> torch.Tensor:
+    """Every rank computes its tile range (balanced by ``costs`` when given), then all ranks hold all blocks."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    rng = tile_range_for_rank(n_tiles, rank, world)
-    return gather_blocks(compute_blocks(rng), n_tiles, group)
+    rng = tile_range_for_rank(n_tiles, rank, world, costs)
+    return gather_blocks(compute_blocks(rng), n_tiles, group, costs)

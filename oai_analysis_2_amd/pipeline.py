@@ -70,8 +70,9 @@ class VolumePipeline:
         its contiguous tile range, ONE all_gather (RCCL) gives every rank all kept-centre blocks, then stitch."""
         from . import parallel
         _, _, n_tiles = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
+        costs = self.unet.tile_costs(vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)     # border tiles are cheaper: balance the work
         blocks = parallel.segment_tile_sharded(
-            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx), n_tiles, group)
+            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx), n_tiles, group, costs)
         return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
 
     def run_sharded(self, vol: torch.Tensor, meta_A: Image, group=None) -> VolumeResult:

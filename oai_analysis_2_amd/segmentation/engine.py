@@ -163,6 +163,14 @@ class UNetEngine:
         return float(self.lib.oai_unet_volume_flops(self._h, *[int(v) for v in size_zyx], _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
                                                     _lib.int3(crop_zyx) if crop_zyx is not None else None, int(trimmed), int(conv3_only)))
 
+    def tile_costs(self, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None):
+        """FLOPs of each tile as ``segment_tiles`` computes it (list of floats, the reference's z-major tile order)."""
+        _, _, n = tile_grid(size_zyx, tile_zyx, overlap_zyx)
+        out = (C.c_double * n)()
+        _lib.check(self.lib.oai_unet_tile_costs(self._h, *[int(v) for v in size_zyx], _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
+                                                _lib.int3(crop_zyx) if crop_zyx is not None else None, out, n), "oai_unet_tile_costs")
+        return list(out)
+
     def segment_tiles(self, vol: torch.Tensor, tile_zyx, overlap_zyx, tile_range: Optional[Tuple[int, int]] = None,
                       out_mode: int = 0, batch: Optional[int] = None, crop_zyx=None) -> torch.Tensor:
         """Kept-centre blocks [n_local, n_classes, ez, ey, ex] of tiles [begin,end) of the volume.

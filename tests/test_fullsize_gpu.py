@@ -47,6 +47,15 @@ def test_full_volume_properties(full):
     from oai_analysis_2_amd.parallel import tile_range_for_rank
     parts = [eng.segment_tiles(v, TILE, OVL, tile_range_for_rank(160, r, 8), 0, 20, CROP) for r in range(8)]
     assert torch.equal(eng.stitch(torch.cat(parts), SHAPE, TILE, OVL, CROP), prob)
+    # ... and the cost-balanced split (border tiles are cheaper) covers the same tiles with equal work per rank
+    costs = eng.tile_costs(SHAPE, TILE, OVL, CROP)
+    assert len(costs) == 160 and abs(sum(costs) - eng.volume_flops(SHAPE, TILE, OVL, CROP)) < 1e-6 * sum(costs)
+    assert min(costs) < 0.75 * max(costs) and costs[0] == min(costs)                  # a corner tile vs an interior tile
+    ranges = [tile_range_for_rank(160, r, 8, costs) for r in range(8)]
+    work = [sum(costs[b:e]) for b, e in ranges]
+    assert max(work) - min(work) <= max(costs) and ranges[0][1] - ranges[0][0] > 20
+    parts = [eng.segment_tiles(v, TILE, OVL, rg, 0, 24, CROP) for rg in ranges]
+    assert torch.equal(eng.stitch(torch.cat(parts), SHAPE, TILE, OVL, CROP), prob)
     # border-tile trimming off (crop unknown to the segment call) computes more but stitches to the same maps
     untrimmed = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=0, batch=16), SHAPE, TILE, OVL, CROP)
     assert torch.equal(untrimmed, prob)

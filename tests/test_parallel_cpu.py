@@ -25,6 +25,25 @@ def test_tile_ranges_cover_exactly():
     assert parallel.volumes_for_rank(10, 1, 4) == [1, 5, 9]
 
 
+def test_cost_weighted_tile_ranges():
+    """ranges stay contiguous and ordered; each rank's work is within one tile of the ideal share; skewed costs move the cuts"""
+    rng = np.random.default_rng(0)
+    for n, w in ((160, 8), (75, 4), (7, 3), (5, 8)):
+        costs = rng.uniform(0.5, 2.0, n).tolist()
+        rs = [parallel.tile_range_for_rank(n, r, w, costs) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        share = sum(costs) / w
+        for b, e in rs:
+            assert abs(sum(costs[b:e]) - share) <= max(costs) + 1e-9
+    # the BASELINE geometry: z-rows 0 and 9 are cheap border rows -> the edge ranks take more tiles than 20
+    costs = [0.6 if i // 16 in (0, 9) else 1.0 for i in range(160)]
+    rs = [parallel.tile_range_for_rank(160, r, 8, costs) for r in range(8)]
+    assert rs[0][1] - rs[0][0] > 20 and rs[7][1] - rs[7][0] > 20 and rs[3][1] - rs[3][0] < 20
+    assert parallel.tile_range_for_rank(160, 3, 8, [1.0] * 160) == (60, 80)        # uniform costs = the count split
+    with pytest.raises(ValueError):
+        parallel.tile_range_for_rank(10, 0, 2, [1.0] * 9)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -51,20 +70,22 @@ def _worker(rank, world, port, n_tiles, out_dir):
         t = g["tile"]
         return torch.sigmoid(logits)[:, :, o[0]:t[0] - o[0], o[1]:t[1] - o[1], o[2]:t[2] - o[2]].contiguous()
 
-    blocks = parallel.segment_tile_sharded(compute, n_tiles)
+    costs = [1.0 + (i % 5) for i in range(n_tiles)] if os.environ.get("OAI_TEST_COSTS") == "1" else None
+    blocks = parallel.segment_tile_sharded(compute, n_tiles, None, costs)
     np.save(os.path.join(out_dir, f"blocks_{rank}.npy"), blocks.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_tile_shard_gather_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,weighted", [(2, False), (4, False), (3, True)])
+def test_tile_shard_gather_matches_single_process(tmp_path, world, weighted, monkeypatch):
     from oracle import seg as oseg
     vol = make_volume(9, (12, 40, 40))
     sd = make_unet_state_dict(seed=2, width_div=4)
     tiles, g = oseg.partition(vol, (16, 16, 8), (4, 4, 2))
     n_tiles = g["n_tiles"]
-    assert n_tiles % world != 0                         # both exercise the ragged, padded gather
+    assert weighted or n_tiles % world != 0             # ragged ranges (by count, or by cost) -> the padded gather
+    monkeypatch.setenv("OAI_TEST_COSTS", "1" if weighted else "0")          # (inherited by the spawned ranks)
     o, t = g["overlap"], g["tile"]
     ref = torch.sigmoid(oseg.unet_forward(torch.from_numpy(tiles), sd))[:, :, o[0]:t[0] - o[0], o[1]:t[1] - o[1], o[2]:t[2] - o[2]].numpy()
     mp.spawn(_worker, args=(world, _free_port(), n_tiles, str(tmp_path)), nprocs=world, join=True)
