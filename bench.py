@@ -6,36 +6,89 @@ overlap-tiled 3D U-Net segmentation (160 tiles of 128x128x32, reference tiling) 
 registration to the atlas (one direction, what ICON_Registration.register returns) -> both probability
 maps pulled onto the atlas grid through phi.  Inputs are resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its N ranks itself, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, volumes are independent units (the reference's own Dask model), every rank
-processes its own volume per step, no data-path collective ("scaling": "weak").  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL.  --mode replicas (default): volumes are independent units (the reference's own
+Dask model), every rank processes its own volume per step, no data-path collective ("scaling": "weak").
+--mode tileshard: every step is ONE volume: broadcast from rank 0, its 160 tiles split over the ranks, one all_gather,
+the phi-resample sharded by atlas z-slab ("scaling": "strong").  Rank 0 prints ONE JSON line.
+
+--dry-run: no GPU, no kernels: the launcher, the rendezvous and the collectives of oai_analysis_2_amd.parallel run on CPU
+tensors over gloo with a stand-in per-rank compute (CI check of the multi-process plumbing; "value" is null).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 VOL_SHAPE = (160, 384, 384)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
-MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense 16-bit MFMA
 PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}
 SUSTAINED_16BIT_MFMA_TFLOPS = 1857.0   # scripts/micro/mfma_peak.hip on this chip: operands in registers, every CU (profiles/r01_ablation.md)
+KERNEL_OF = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_igemm_sres (split-resident fp16x3)",
+             "bf16x3": "conv3_igemm_bf16s (split 16-bit)", "bf16x6": "conv3_igemm_bf16s (split 16-bit)"}
+DTYPE_OF = {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
+            "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
+            "fp16x3": "fp16x3 (every fp32 value held as 2 fp16 terms = 22 mantissa bits, 3 MFMA passes per product, fp32 accumulate; "
+                      "fp32 in and out of every entry point; full-size parity vs the reference in `parity`)"}
+TRAFFIC_FILE = {"f32": "profiles/r01_pmc_traffic.json", "fp16x3": "profiles/r01_pmc_traffic_sres.json"}
+
+
+def physical_cores() -> int:
+    """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo); BASELINE.md 3 asks for this, not SMT threads."""
+    try:
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of torch.distributed.run and return
+    their exit code.  Nothing here touches the GPU (a process that has initialised HIP must not exec or fork GPU work)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
-    """The oracle (CPU port of the reference algorithm) timed on this host, on a bounded sample."""
+    """The oracle (CPU port of the reference algorithm) timed on this host's physical cores, on a bounded sample."""
+    import numpy as np
+    import torch
     from oai_analysis_2_amd.image import Image
     from oracle import icon as oicon, resample as oresample, seg as oseg
-    threads = torch.get_num_threads()
+    cores = physical_cores()
+    torch.set_num_threads(cores)
     tiles, g = oseg.partition(vol_np, (128, 128, 32), (16, 16, 8))
     x = torch.from_numpy(np.ascontiguousarray(tiles[:n_tiles_sample]))
     oseg.unet_forward(x[:1], unet_sd)                                    # warm-up
@@ -53,10 +106,115 @@ def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
     oresample.resample_through_phi(vol_np.astype(np.float64), disp, meta_A, sub)
     t_res = (time.time() - t0) * (atlas_img.array.shape[0] / zs) * 2      # FC and TC
     t_vol = g["n_tiles"] * t_tile + t_reg + t_res
-    return {"value": 1.0 / t_vol, "unit": "volumes/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / t_vol, "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{n_tiles_sample} of {g['n_tiles']} U-Net tiles (x{g['n_tiles'] / n_tiles_sample:.0f}), "
                       f"1 full ICON direction, {zs}/{atlas_img.array.shape[0]} slices of one resample (x{2 * atlas_img.array.shape[0] // zs}); "
-                      f"s/tile={t_tile:.2f} s_register={t_reg:.1f} s_resample={t_res:.1f}"}
+                      f"s/tile={t_tile:.2f} s_register={t_reg:.1f} s_resample={t_res:.1f}; torch threads = physical cores"}
+
+
+def fullsize_parity(unet, precision):
+    """The segmentation of the golden volume in `precision` against tests/golden/segment_fullsize.npz -- the REFERENCE's own
+    segment() run on CPU at 384x384x160 (tests/golden/make_golden_fullsize.py).  Data fixture, not the oracle; outside the
+    timed region.  The same comparison is asserted by tests/test_fullsize_gpu.py."""
+    import hashlib
+    import numpy as np
+    import torch
+    from oai_analysis_2_amd.pipeline import CROP_ZYX, OVERLAP_ZYX, TILE_ZYX
+    from oai_analysis_2_amd.synth import make_volume
+    path = os.path.join(ROOT, "tests", "golden", "segment_fullsize.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    vol = make_volume(int(z["volume_seed"]), VOL_SHAPE)
+    same_input = hashlib.sha256(vol.tobytes()).digest() == bytes(z["volume_sha256"])
+    prev = unet.precision
+    unet.set_precision(precision)
+    v = torch.from_numpy(vol).cuda()
+    prob = unet.stitch(unet.segment_tiles(v, TILE_ZYX, OVERLAP_ZYX, out_mode=0, crop_zyx=CROP_ZYX), VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX)
+    mask = unet.stitch(unet.segment_tiles(v, TILE_ZYX, OVERLAP_ZYX, out_mode=1, crop_zyx=CROP_ZYX), VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX)
+    unet.set_precision(prev)
+    prob, mask = prob.cpu().numpy(), mask.cpu().numpy() > 0.5
+    ref_mask = np.stack([np.unpackbits(z["fc_mask_bits"])[:vol.size], np.unpackbits(z["tc_mask_bits"])[:vol.size]]).astype(bool).reshape(2, *VOL_SHAPE)
+    flips = np.flatnonzero((mask != ref_mask).ravel())
+    near = dict(zip(z["near_idx"].tolist(), z["near_prob"].tolist()))
+    worst = max((abs(near.get(int(i), 0.0) - 0.5) for i in flips), default=0.0)
+    sl = tuple(slice(int(a), None, int(s)) for a, s in zip(z["start"], z["stride"]))
+    ref_s = np.stack([z["fc_prob_s"], z["tc_prob_s"]]).astype(np.float64)
+    got_s = np.stack([prob[0][sl], prob[1][sl]]).astype(np.float64)
+    dsum = np.abs(got_s - ref_s).sum(axis=(1, 2, 3))
+    scale = vol.size / ref_s[0].size
+    return {"against": "tests/golden/segment_fullsize.npz = the reference's Segmenter3DInPatchClassWise.segment on CPU, 384x384x160, seeded weights",
+            "precision": precision, "input_bit_identical": bool(same_input), "mask_voxels": int(2 * vol.size),
+            "mask_flips": int(len(flips)), "max_abs_pref_minus_half_at_flips": float(worst),
+            "flips_with_pref_farther_than_1e-5_from_half": int(sum(1 for i in flips if abs(near.get(int(i), 0.0) - 0.5) >= 1e-5)),
+            "sum_abs_dp_per_23.6M_voxels": [float(d * scale) for d in dsum], "reference_budget_sum_abs_dp": 12.0,
+            "max_abs_dp_sample": float(np.abs(got_s - ref_s).max()), "sample_voxels_per_map": int(ref_s[0].size)}
+
+
+def dry_run(args, world, rank):
+    """CPU/gloo check of the multi-process plumbing: broadcast, cost-balanced tile shard + all_gather, flag agreement,
+    z-slab gather, max-over-ranks timing -- the product's own parallel.py on CPU tensors, with a stand-in compute."""
+    import torch
+    import torch.distributed as dist
+    from oai_analysis_2_amd import parallel
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    shape, n_tiles, nz = (8, 12, 12), 23, 10
+    vol = torch.arange(8 * 12 * 12, dtype=torch.float32).reshape(shape) if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        if args.mode == "tileshard":
+            v = parallel.broadcast_volume(vol, shape, "cpu", 0) if world > 1 else vol
+            costs = [1.0 + (i % 4 == 0) for i in range(n_tiles)]
+            blocks = parallel.segment_tile_sharded(lambda rg: torch.stack([v.sum() + t * torch.ones(2, 2, 3, 3) for t in range(*rg)])
+                                                   if rg[1] > rg[0] else torch.zeros(0, 2, 2, 3, 3), n_tiles, None, costs)
+            assert blocks.shape[0] == n_tiles and all(float(blocks[t, 0, 0, 0, 0]) == float(v.sum()) + t for t in range(n_tiles))
+            flag = parallel.any_rank(torch.tensor([1 if rank == world - 1 else 0], dtype=torch.int32))
+            assert int(flag) == 1
+            b, e = parallel.slab_range_for_rank(nz, rank, world)
+            slabs = parallel.gather_slabs(torch.arange(b, e, dtype=torch.float32)[None, :, None, None].expand(2, e - b, 3, 3).contiguous(), nz)
+            assert slabs.shape == (2, nz, 3, 3) and torch.equal(slabs[0, :, 0, 0], torch.arange(nz, dtype=torch.float32))
+        else:
+            mine = parallel.volumes_for_rank(world * 2, rank, world)
+            assert mine == [rank, rank + world]
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32", "value": None, "unit": "volumes/s",
+                          "dry_run": True, "backend": "gloo" if world > 1 else None, "world_size": world, "n_gpus": 0,
+                          "mode": args.mode, "steps": args.steps, "warmup": args.warmup, "seconds": float(dt)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure(step, unet, steps, warmup, use_dist, dist):
+    """W untimed + K timed steps, barrier + synchronize on both sides; returns (seconds, conv ms, conv launches)."""
+    import torch
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    unet.profile_read()
+    unet.profile(True)                                                    # HIP events around the dominant kernel, on its stream
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    flags = []
+    for i in range(steps):
+        flags.append(step(i).overflow)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_launches = unet.profile_read()
+    unet.profile(False)
+    overflow = any(int(f.item()) for f in flags if f is not None)      # the per-volume fp16 range flags, read after the timed region
+    return dt, conv_ms, conv_launches, overflow
 
 
 def main():
@@ -67,24 +225,40 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="tiles per U-Net pass (sizes the activation workspace); 0 = all that fit in 60%% of free HBM")
     ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "f32", "bf16x6", "bf16x3"],
                     help="arithmetic of the 3x3x3 conv layers.  fp16x3 (default): every fp32 operand split into two fp16 terms, "
-                         "3 MFMA passes, fp32 accumulate -- fp32-grade results (same parity margins as f32 in tests/); "
-                         "f32: exact fp32 MFMA; bf16x6 / bf16x3: split-bf16 with 6 / 3 passes")
+                         "3 MFMA passes, fp32 accumulate -- fp32-grade results (same parity margins as f32 in tests/, incl. the full-size "
+                         "reference golden); f32: exact fp32 MFMA; bf16x6 / bf16x3: split-bf16 with 6 / 3 passes")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "tileshard"],
                     help="N>1: replicas = one volume per rank per step (weak scaling, no collective); tileshard = every step "
                          "is ONE volume whose 160 tiles are split over the ranks + one RCCL all_gather (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x6 measurement reported beside the fp32 one")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in exact fp32 MFMA (full --steps) reported beside the primary")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of launcher + collectives, no GPU, no kernels")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ                                 # started by torch.distributed.run (also with one rank)
+    if not launched and args.gpus > 1:
+        if not args.dry_run:
+            import torch                                                   # device_count() does not initialise the GPU on this image
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr)
+                raise SystemExit(2)
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        print(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}", file=sys.stderr)
+        raise SystemExit(2)
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    use_dist = "WORLD_SIZE" in os.environ          # launched by torch.distributed.run (also with one rank)
+    use_dist = launched
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -111,29 +285,13 @@ def main():
     meta = Image(vols_np[0], [0.36, 0.36, 0.7], [2.0, -3.0, 1.0])
 
     def step(i):
+        # check=False: the per-volume fp16 range flag is snapshotted on the device and read after the timed region (what
+        # CohortRunner does at download time), so that no host synchronisation sits between volumes
         if args.mode == "tileshard":
-            return pipe.run_sharded(vols[i % n_distinct], meta)
-        return pipe.run(vols[i % n_distinct], meta)
+            return pipe.run_sharded(vols[i % n_distinct] if rank == 0 else None, meta, check=False)   # the volume lives on rank 0: broadcast inside
+        return pipe.run(vols[i % n_distinct], meta, check=False)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    unet.profile_read()
-    unet.profile(True)                                                    # HIP events around the dominant kernel
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    conv_ms, conv_launches = unet.profile_read()
-    unet.profile(False)
-    overflow = unet.range_overflow() if args.precision == "fp16x3" else False
+    dt, conv_ms, conv_launches, overflow = measure(step, unet, args.steps, args.warmup, use_dist, dist)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,80 +311,61 @@ def main():
         # beside it (achieved_frame_aware) so that nothing is overstated.
         survey_conv3 = unet.tile_flops_conv3(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles
         vol_conv3 = unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, True)
-        alg_conv3 = survey_conv3 * my_frac * args.steps
-        achieved = alg_conv3 / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        achieved_fa = achieved * vol_conv3 / survey_conv3
-        peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_BF16_PEAK_TFLOPS
-        def traffic_of(prec):     # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes (profiles/)
+
+        def traffic_of(prec):     # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes, so this is READ FROM profiles/
             try:
-                if prec not in ("f32", "fp16x3"):
-                    return None
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if prec == "f32" else "r01_pmc_traffic_sres.json")) as f:
+                with open(os.path.join(ROOT, TRAFFIC_FILE[prec])) as f:
                     # the counters were collected on 32-tile passes; a launch of this run covers `last_batch` tiles
                     return json.load(f)["bytes_per_launch"] * getattr(unet, "last_batch", 32) / 32.0
             except (OSError, KeyError, ValueError):
                 return None
-        kernel_of = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_igemm_sres (split-resident fp16x3)",
-                     "bf16x3": "conv3_igemm_bf16s (split 16-bit)", "bf16x6": "conv3_igemm_bf16s (split 16-bit)"}
-        clock_note = ("the 16-bit MFMA path is power-limited on this workload: sclk 1.96 GHz at ~1.28 kW (profiles/r01_power.md), "
-                      "i.e. a dense peak of 2.05 PFLOP/s at the clock it runs at; `peak` stays the nominal 2.5 PFLOP/s")
+
+        def roofline(prec, ms, launches, steps, frac_of_volume):
+            alg = survey_conv3 * frac_of_volume * steps
+            ach = alg / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            ach_fa = ach * vol_conv3 / survey_conv3
+            peak = MFMA_F32_PEAK_TFLOPS if prec == "f32" else MFMA_BF16_PEAK_TFLOPS
+            return {"bound": "mfma", "kernel": KERNEL_OF[prec], "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": traffic_of(prec),
+                    "traffic_source": (TRAFFIC_FILE.get(prec, "none") + " (rocprofv3 --pmc, separate pass, 32-tile launches scaled to this launch size; "
+                                       "NOT measured in this run)") if traffic_of(prec) is not None else None,
+                    "achieved_frame_aware": ach_fa, "frac_frame_aware": ach_fa / peak,
+                    "mfma_passes_per_product": PASSES[prec], "executed_frac": ach_fa * PASSES[prec] / peak,
+                    "executed_frac_of_sustained_issue_rate": None if prec == "f32" else ach_fa * PASSES[prec] / SUSTAINED_16BIT_MFMA_TFLOPS,
+                    "algorithmic_flops_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                    "clock_note": None if prec == "f32" else
+                    "the 16-bit MFMA path is power-limited on this workload: sclk 1.96 GHz at ~1.28 kW (profiles/r01_power.md), i.e. a "
+                    "dense peak of 2.05 PFLOP/s at the clock it runs at; `peak` stays the nominal 2.5 PFLOP/s",
+                    "concurrency_note": "the ICON registration kernels of the same volume run on a side stream underneath these launches"}
+
         out = {
             "metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32",
             "value": (world if args.mode == "replicas" else 1) * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
-                      "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
-                      "fp16x3": "fp16x3 (every fp32 value held as 2 fp16 terms = 22 mantissa bits, 3 MFMA passes per product, fp32 accumulate; "
-                                "fp32 in and out of every entry point)"}[args.precision], "data": "synthetic",
+            "dtype": DTYPE_OF[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
-                       "tiles_per_pass": getattr(unet, "last_batch", args.batch), "parallelism": f"{args.mode} x{world}"},
-            "roofline": {"bound": "mfma", "kernel": kernel_of[args.precision],
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic_of(args.precision),
-                         "clock_note": None if args.precision == "f32" else clock_note,
-                         "concurrency_note": "the ICON registration kernels of the same volume run on a side stream underneath these "
-                                             "launches (OAI_OVERLAP_REG=0 serialises: +1.5 % on volumes/s, the conv launches measure ~2 % longer)",
-                         "achieved_frame_aware": achieved_fa, "frac_frame_aware": achieved_fa / peak,
-                         "mfma_passes_per_product": PASSES[args.precision],
-                         "executed_frac": achieved_fa * PASSES[args.precision] / peak,
-                         "executed_frac_of_sustained_issue_rate": None if args.precision == "f32" else
-                         achieved_fa * PASSES[args.precision] / SUSTAINED_16BIT_MFMA_TFLOPS,
-                         "algorithmic_flops_per_launch": alg_conv3 / max(conv_launches, 1),
-                         "avg_launch_ms": conv_ms / max(conv_launches, 1), "launches": conv_launches},
+                       "tiles_per_pass": getattr(unet, "last_batch", args.batch), "parallelism": f"{args.mode} x{world}",
+                       "collective_backend": ("nccl (RCCL)" if use_dist else None), "world_size": world},
+            "roofline": roofline(args.precision, conv_ms, conv_launches, args.steps, my_frac),
             "fp16_range_overflow": overflow,
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
             "segment_frame_aware_tflop_per_volume": unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, False) / 1e12,
         }
+        if world == 1 and not args.no_parity:
+            out["parity"] = fullsize_parity(unet, args.precision)
         if world == 1 and not args.no_alt:
-            # the same workload with the other arithmetic (exact fp32 MFMA when the primary is split-fp16, and vice versa);
-            # reported beside the primary number, never as `value`
+            # the SAME workload, same --steps / --warmup, with the other arithmetic (exact fp32 MFMA when the primary is split-fp16):
+            # a first-class measurement, so that a reader who only credits reference-precision arithmetic has a number
             alt = "f32" if args.precision != "f32" else "fp16x3"
             unet.set_precision(alt)
-            step(0)
-            torch.cuda.synchronize()
-            unet.profile_read()
-            unet.profile(True)
-            ta = time.perf_counter()
-            n_alt = min(2, args.steps)
-            for i in range(n_alt):
-                step(i)
-            torch.cuda.synchronize()
-            dta = time.perf_counter() - ta
-            ms_a, n_a = unet.profile_read()
-            unet.profile(False)
+            dta, ms_a, n_a, ov_a = measure(step, unet, args.steps, args.warmup, False, dist)
             unet.set_precision(args.precision)
-            ach = survey_conv3 * n_alt / (ms_a * 1e-3) / 1e12
-            pk = MFMA_F32_PEAK_TFLOPS if alt == "f32" else MFMA_BF16_PEAK_TFLOPS
-            out["alt_precision"] = {"precision": alt, "value": n_alt / dta, "unit": "volumes/s", "ms_per_step": 1e3 * dta / n_alt,
-                                    "roofline": {"bound": "mfma", "kernel": kernel_of[alt],
-                                                 "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, "traffic": traffic_of(alt),
-                                                 "achieved_frame_aware": ach * vol_conv3 / survey_conv3,
-                                                 "mfma_passes_per_product": PASSES[alt],
-                                                 "executed_frac": PASSES[alt] * ach * vol_conv3 / survey_conv3 / pk},
-                                    "parity": "same gates as the primary mode (tests/test_unet_gpu.py: logits <= 1e-4 rel, "
-                                              "sum|dp| < 12 per 23.6M voxels)"}
+            out["fp32_mfma" if alt == "f32" else "alt_precision"] = {
+                "precision": alt, "dtype": DTYPE_OF[alt], "value": args.steps / dta, "unit": "volumes/s", "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * dta / args.steps, "roofline": roofline(alt, ms_a, n_a, args.steps, 1.0),
+                "parity": None if args.no_parity else fullsize_parity(unet, alt)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vols_np[0], meta, atlas, unet_sd, icon_sd)
         print(json.dumps(out), flush=True)

@@ -82,6 +82,17 @@ int oai_resample_through_disp(const float* prob_dev, int nzA, int nyA, int nxA,
                               const oai_affine* b_index_to_net, const oai_affine* net_to_a_index,
                               float* out_dev, int nzB, int nyB, int nxB, void* stream);
 
+/* The same resample for n_maps (1..4) probability maps probs_dev[n_maps][nzA][nyA][nxA] at once, straight from the network's
+ * dense map phi_dev[3][Dn][Hn][Wn] (fp32, [0,1] units): create_itk_transform's displacement (fp32 arithmetic, widened to
+ * double -- the value oai_phi_to_itk_displacement stores) is rebuilt at the 8 corners in registers, so neither the 71 MB
+ * fp64 field nor a second pass over phi exists.  Results are bit-identical to oai_phi_to_itk_displacement +
+ * oai_resample_through_disp per map.  Replaces the two deform_probmap calls of test/test_all.py:54-58 /
+ * dask_processing.py:95-111.  out_dev[n_maps][nzB][nyB][nxB]. */
+int oai_resample_maps_through_phi(const float* probs_dev, int n_maps, int nzA, int nyA, int nxA,
+                                  const float* phi_dev, int Dn, int Hn, int Wn,
+                                  const oai_affine* b_index_to_net, const oai_affine* net_to_a_index,
+                                  float* out_dev, int nzB, int nyB, int nxB, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Intensity windowing, the step just before the hot path: image_normalize(image, lo, hi, omin, omax) of
  * oai_analysis/dask_processing.py:10-26 (called with 0.1, 99.9, 0, 1 at :75 and :177) =
@@ -137,8 +148,20 @@ void oai_unet_destroy(oai_unet* h);
                              activations below 65504 in magnitude (weights are range-scaled per output channel, exactly) */
 int oai_unet_set_precision(oai_unet* h, int mode);
 /* OAI_PREC_FP16X3 only: *out = 1 if, since the last reset, some activation was outside fp16's range (the results of
- * that run are then invalid: rerun it with OAI_PREC_F32 or OAI_PREC_BF16X6).  Blocks until prior work has finished. */
-int oai_unet_range_flag(oai_unet* h, int reset, int* out);
+ * that run are then invalid: rerun it with OAI_PREC_F32 or OAI_PREC_BF16X6).  The read (and the reset) are ordered on
+ * `stream` -- pass the stream the segment calls were queued on -- and the call blocks until that stream has drained. */
+int oai_unet_range_flag(oai_unet* h, int reset, int* out, void* stream);
+/* Asynchronous form for pipelined callers (cohort.py): copies the flag word to dst_dev[0] and clears it, both queued on
+ * `stream` behind the segment calls of ONE volume, so the flag is attributed to that volume; the caller reads dst_dev
+ * with its own D2H copy of the results.  No synchronisation. */
+int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream);
+/* Result-preserving tuning options of the OAI_PREC_FP16X3 path, by name (the library does not read the environment):
+ *   "sres" 0|1 (1)      activations resident as fp16 term pairs (unet_sres.h) / fp32-resident split kernels
+ *   "sres_mrep" 2|4 (4) z slices per workgroup of the split-resident conv kernel
+ *   "sres_ring" 0|1 (0) six-slot z-plane ring staging (implies sres_mrep 2)
+ *   "xcd_group" n (32)  logical blocks dealt to one XCD at a time; 0 = plain launch order
+ * Unknown names and out-of-range values return OAI_ERR_ARG. */
+int oai_unet_set_option(oai_unet* h, const char* name, int value);
 
 /* Bytes of device scratch oai_unet_forward_* needs for `batch` tiles of (td,th,tw). */
 size_t oai_unet_workspace_bytes(const oai_unet* h, int td, int th, int tw, int batch);

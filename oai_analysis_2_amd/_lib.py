@@ -45,6 +45,8 @@ SIGNATURES = {
     "oai_phi_to_itk_displacement": (_I, [_P, _I, _I, _I, _P, _P]),
     "oai_resample_through_disp": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
                                        _P, _I, _I, _I, _P]),
+    "oai_resample_maps_through_phi": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
+                                           _P, _I, _I, _I, _P]),
     "oai_unet_tile_costs": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),
     "oai_mc_table": (_I, [_P]),
     "oai_mc_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -59,7 +61,9 @@ SIGNATURES = {
     "oai_unet_create": (_I, [C.POINTER(LayerParams), _F, C.POINTER(_P)]),
     "oai_unet_destroy": (None, [_P]),
     "oai_unet_set_precision": (_I, [_P, _I]),
-    "oai_unet_range_flag": (_I, [_P, _I, C.POINTER(_I)]),
+    "oai_unet_range_flag": (_I, [_P, _I, C.POINTER(_I), _P]),
+    "oai_unet_range_flag_snapshot": (_I, [_P, _P, _P]),
+    "oai_unet_set_option": (_I, [_P, C.c_char_p, _I]),
     "oai_unet_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
     "oai_unet_forward_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),

@@ -29,12 +29,26 @@ def data_dir() -> str:
 
 
 def load_atlas(path: str) -> Image:
-    """atlas_image.npz: array [z,y,x] + spacing/origin/direction (NIfTI needs itk, absent here)."""
+    """atlas_image.npz (array [z,y,x] + spacing/origin/direction) or a NIfTI file read by this package's own reader
+    (io_nifti.read_nifti: ITK's LPS conventions; itk itself is not needed)."""
     if path.endswith(".npz"):
         z = np.load(path)
         return Image(z["array"], z["spacing"], z["origin"], z["direction"])
-    import itk  # pragma: no cover
-    return as_image(itk.imread(path))
+    from .io_nifti import read_nifti
+    return read_nifti(path)
+
+
+def asset_paths(root: str) -> dict:
+    """Where the reference's three release tarballs (data.py:8-22, tag v2.0.0) put things when extracted under ``root`` --
+    ``models/``, ``atlases/``, ``test_data/`` -- with a flat directory (everything next to each other) as the fallback."""
+    models = os.path.join(root, "models") if os.path.isdir(os.path.join(root, "models")) else root
+    atlas = os.path.join(root, "atlases", "atlas_60_LEFT_baseline_NMI", "atlas_image.nii.gz")     # analysis_object.py:40
+    if not os.path.exists(atlas):
+        atlas = os.path.join(models, "atlas_image.npz")
+    return {"ckpoint_path": os.path.join(models, "segmentation_model.pth.tar"),
+            "training_config_file": os.path.join(models, "segmentation_train_config.pth.tar"),
+            "icon_weights": os.environ.get("OAI_ICON_WEIGHTS") or os.path.join(models, "icon_weights.pth"),
+            "atlas": atlas, "test_case": os.path.join(root, "test_data", "colab_case")}
 
 
 class AnalysisObject:
@@ -42,10 +56,10 @@ class AnalysisObject:
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: oai_analysis_2_amd is the MI355X path and has no CPU fallback")
         self.device = device or "cuda"
-        models = models_dir or data_dir()
+        paths = asset_paths(models_dir or data_dir())
         segmenter_config = dict(                                    # the literals of analysis_object.py:18-26
-            ckpoint_path=os.path.join(models, "segmentation_model.pth.tar"),
-            training_config_file=os.path.join(models, "segmentation_train_config.pth.tar"),
+            ckpoint_path=paths["ckpoint_path"],
+            training_config_file=paths["training_config_file"],
             device=self.device,
             batch_size=4,
             overlap_size=(16, 16, 8),
@@ -53,9 +67,8 @@ class AnalysisObject:
             output_itk=True,
         )
         self.segmenter = Segmenter3DInPatchClassWise(mode="pred", config=segmenter_config)
-        self.registerer = ICON_Registration(weights=icon_weights if icon_weights is not None
-                                            else os.path.join(models, "icon_weights.pth"), device=self.device)
-        self.atlas_image = as_image(atlas_image) if atlas_image is not None else load_atlas(os.path.join(models, "atlas_image.npz"))
+        self.registerer = ICON_Registration(weights=icon_weights if icon_weights is not None else paths["icon_weights"], device=self.device)
+        self.atlas_image = as_image(atlas_image) if atlas_image is not None else load_atlas(paths["atlas"])
 
     def segment(self, preprocessed_image):
         FC_probmap, TC_probmap = self.segmenter.segment(preprocessed_image, if_output_prob_map=True, if_output_itk=True)

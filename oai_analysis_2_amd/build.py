@@ -39,7 +39,10 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+def build_library(force: bool = False, verbose: bool = True, extra_flags=(), lib_path: str = None, obj_dir: str = None) -> str:
+    """Production build by default.  ``build_diag()`` passes -DOAI_DIAG and other output paths: the diagnostic library (timing
+    ablations with wrong results, variant selection by environment) is a separate file that only scripts/ load via OAI_LIB_PATH."""
+    OBJ, LIB = obj_dir or globals()["OBJ"], lib_path or globals()["LIB"]
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "oai_hip.h"))
@@ -76,5 +79,15 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
     return LIB
 
 
+DIAG_LIB = os.path.join(os.path.dirname(HERE), "build", "diag", "liboai_hip_diag.so")
+
+
+def build_diag(force: bool = False, extra_flags=()) -> str:
+    return build_library(force, True, ["-DOAI_DIAG", *extra_flags], DIAG_LIB, os.path.join(os.path.dirname(DIAG_LIB), "_obj"))
+
+
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    if "--diag" in sys.argv:
+        print(build_diag(force="--force" in sys.argv))
+    else:
+        build_library(force="--force" in sys.argv)

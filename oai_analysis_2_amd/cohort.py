@@ -43,12 +43,14 @@ class CohortRunner:
         self._pin_ev[slot] = ev
         return dev, ev
 
-    def _download(self, res: VolumeResult, done: torch.cuda.Event) -> VolumeResult:
-        """D2H of one volume's results on the copy stream (after `done`), through reusable pinned buffers."""
+    def _download(self, res: VolumeResult, done: torch.cuda.Event) -> Optional[VolumeResult]:
+        """D2H of one volume's results on the copy stream (after `done`), through reusable pinned buffers.  The fp16 range flag
+        of the volume rides along (4 bytes); None = it overflowed and the results must not be used."""
         self.copy_stream.wait_event(done)
         outs = []
         with torch.cuda.stream(self.copy_stream):
-            for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
+            names = ("fc", "tc", "phi", "fc_atlas", "tc_atlas") + (("overflow",) if res.overflow is not None else ())
+            for name in names:
                 t = getattr(res, name)
                 key = (name, tuple(t.shape), t.dtype)
                 if key not in self._pin_out:
@@ -57,7 +59,27 @@ class CohortRunner:
                 t.record_stream(self.copy_stream)
                 outs.append(self._pin_out[key])
         self.copy_stream.synchronize()
-        return VolumeResult(*(o.clone() for o in outs))                  # the pinned buffers are reused by the next volume
+        if res.overflow is not None and int(outs[5][0]):
+            return None
+        return VolumeResult(*(o.clone() for o in outs[:5]), repeated_f32=res.repeated_f32)   # the pinned buffers are reused by the next volume
+
+    def _finish(self, pending) -> VolumeResult:
+        """Results of a queued volume; a volume whose fp16x3 segmentation left fp16's range is repeated in exact fp32 here
+        (the check is lazy -- at download time -- so the overlap of the normal case is kept; never silent)."""
+        i, res, done, dev, img = pending
+        if self.keep_on_device:
+            done.synchronize()
+            if res.overflow is not None and int(res.overflow.item()):
+                res = self.pipe.rerun_f32(dev, img)
+                torch.cuda.current_stream().synchronize()
+            return res
+        out = self._download(res, done)
+        if out is None:
+            res = self.pipe.rerun_f32(dev, img)
+            done = torch.cuda.Event()
+            done.record()
+            out = self._download(res, done)
+        return out
 
     def run(self, images: Sequence, rank: int = 0, world: int = 1) -> Iterator[Tuple[int, VolumeResult]]:
         """Yield (index, result) for the volumes this rank owns (index % world == rank), in order."""
@@ -71,18 +93,12 @@ class CohortRunner:
             dev, ev = nxt
             torch.cuda.current_stream().wait_event(ev)
             dev.record_stream(torch.cuda.current_stream())                # allocated on the copy stream, read by the compute stream
-            res = self.pipe.run(dev, imgs[i])                             # queued, not waited for
+            res = self.pipe.run(dev, imgs[i], check=False)                # queued, not waited for; the range flag is read at download time
             done = torch.cuda.Event()
             done.record()
             if k + 1 < len(mine):
                 nxt = self._upload(imgs[mine[k + 1]], (k + 1) & 1)        # host staging + H2D behind this volume's compute
             if pending is not None:
-                pi, pres, pdone = pending
-                yield pi, (pres if self.keep_on_device else self._download(pres, pdone))
-            pending = (i, res, done)
-        pi, pres, pdone = pending
-        if self.keep_on_device:
-            pdone.synchronize()
-            yield pi, pres
-        else:
-            yield pi, self._download(pres, pdone)
+                yield pending[0], self._finish(pending)
+            pending = (i, res, done, dev, imgs[i])
+        yield pending[0], self._finish(pending)

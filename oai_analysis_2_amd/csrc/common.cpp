@@ -1,5 +1,7 @@
 #include "common.h"
 
+#include <cstdlib>
+
 namespace oai {
 
 char* error_buffer() {
@@ -14,6 +16,13 @@ int set_error(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+#ifdef OAI_DIAG
+int diag_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#endif
 
 }  // namespace oai
 

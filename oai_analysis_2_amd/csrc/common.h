@@ -29,4 +29,14 @@ int set_error(int code, const char* fmt, ...);
 
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// Diagnostic switches (timing ablations that produce WRONG results, kernel-variant selection by environment) exist only in
+// builds compiled with -DOAI_DIAG (scripts/build_diag.sh -> a separate .so loaded through OAI_LIB_PATH).  The production
+// library never reads the environment: diag_env() is the constant default and every `OAI_DBG_BIT(...)` branch (unet_kernels.h)
+// folds away.
+#ifdef OAI_DIAG
+int diag_env(const char* name, int dflt);
+#else
+static inline int diag_env(const char*, int dflt) { return dflt; }
+#endif
+
 }  // namespace oai

@@ -38,9 +38,10 @@ struct oai_unet {
     int precision = OAI_PREC_F32;
     int* range_flag = nullptr;          // device word set by the split-fp16 kernels when an activation exceeds fp16's range
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
-    int xcd_group = 32;                 // logical blocks per XCD deal (OAI_XCD_GROUP; 0 = launch order)
-    bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (OAI_SRES_RING=1)
-    int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (OAI_SRES_MREP=2|4; 2 runs three workgroups per CU: -2 % on 32 border tiles, +0.5 % on the whole volume)
+    int xcd_group = 32;                 // logical blocks per XCD deal (option "xcd_group"; 0 = launch order)
+    bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (option "sres_ring")
+    int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (option "sres_mrep" 2|4; 2 runs three workgroups per CU: -2 % on 32 border tiles, +0.5 % on the whole volume)
+    bool opt_sres = true;               // option "sres": fp16x3 uses the split-resident kernels
     bool sres = false;                  // fp16x3 runs split-resident (activations stored as fp16 term pairs, unet_sres.h)
     int n_classes = 0;
     std::vector<void*> allocs;
@@ -332,7 +333,7 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     a.boxes = boxes;
     a.pool_out = pool_out;
     a.range_flag = h->range_flag;
-    { static const int dbg = getenv("OAI_DBG") ? atoi(getenv("OAI_DBG")) : 0; a.dbg = dbg; }
+    { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }      // -DOAI_DIAG builds only; constant 0 otherwise
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
     a.out = out; a.Cout = L.cout; a.scale = h->precision == OAI_PREC_FP16X3 ? L.scale_f16 : L.scale; a.shift = L.shift;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : h->precision == OAI_PREC_BF16X6 ? 1 : 2];
@@ -374,7 +375,7 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.boxes = in_boxes;
     a.range_flag = h->range_flag;
     a.zero = h->zero_rec;
-    { static const int dbg = getenv("OAI_DBG") ? atoi(getenv("OAI_DBG")) : 0; a.dbg = dbg; }
+    { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }
     const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
     a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
     a.wpanel = split ? L.panel_bf[2] : L.panel;
@@ -481,7 +482,7 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     // in dc1's epilogue (dc1's 64 output channels sit in one workgroup): no dc1 output round trip through HBM, no head launch.
     const int kz = src.vol ? src.oz : 0, ky = src.vol ? src.oy : 0, kx = src.vol ? src.ox : 0;
     const int ez = src.vol ? src.ez : src.td, ey = src.vol ? src.ey : src.th, ex = src.vol ? src.ex : src.tw;
-    static const bool no_fuse = getenv("OAI_NO_HEAD_FUSE") != nullptr;
+    static const bool no_fuse = diag_env("OAI_NO_HEAD_FUSE", 0) != 0;
     const bool fuse_head = h->sres && !no_fuse && L[DC1].cout <= 64 && L[DC0].cin == L[DC1].cout && h->n_classes <= 4 &&
                            need[DC1].lo[0] <= need[DC0].lo[0] && need[DC1].hi[0] >= need[DC0].hi[0];
     if (fuse_head) {
@@ -558,8 +559,8 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
         h->zero_rec = reinterpret_cast<unsigned char*>(z);
         (void)hipMemset(z, 0, 256);
     }
-    const char* env = getenv("OAI_CONV_VARIANT");
-    h->variant = env ? atoi(env) : 0;
+    h->variant = diag_env("OAI_CONV_VARIANT", 0);
+    if (h->variant < 0 || h->variant > 2) h->variant = 0;
     h->n_classes = layers[DC0].cout;
     const int KC = conv_kc(h->variant);
     int rc = OAI_OK;
@@ -645,22 +646,51 @@ int oai_unet_set_precision(oai_unet* h, int mode) {
         }
     }
     h->precision = mode;
-    const char* sres_env = getenv("OAI_SRES");
-    h->sres = mode == OAI_PREC_FP16X3 && !(sres_env && atoi(sres_env) == 0);
-    const char* mrep_env = getenv("OAI_SRES_MREP");
-    h->sres_mrep = mrep_env && atoi(mrep_env) == 2 ? 2 : 4;
-    const char* xg_env = getenv("OAI_XCD_GROUP");
-    h->xcd_group = xg_env ? atoi(xg_env) : 32;
-    const char* ring_env = getenv("OAI_SRES_RING");
-    h->sres_ring = ring_env && atoi(ring_env) == 1;
-    if (h->sres_ring) h->sres_mrep = 2;
+    h->sres = mode == OAI_PREC_FP16X3 && h->opt_sres;
     return OAI_OK;
 }
 
-int oai_unet_range_flag(oai_unet* h, int reset, int* out) {
+// Result-preserving tuning options of the fp16x3 path (every combination is parity-tested: tests/test_unet_gpu.py).  An explicit
+// call on the handle -- the production library does not read the environment.
+int oai_unet_set_option(oai_unet* h, const char* name, int value) {
+    OAI_CHECK_ARG(h && name, "oai_unet_set_option: null pointer");
+    if (!strcmp(name, "sres")) {                       // 1: activations resident as fp16 term pairs (default); 0: fp32-resident split kernels
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: sres must be 0 or 1");
+        h->opt_sres = value != 0;
+        h->sres = h->precision == OAI_PREC_FP16X3 && h->opt_sres;
+    } else if (!strcmp(name, "sres_mrep")) {           // z slices per block of the split-resident conv kernel
+        OAI_CHECK_ARG(value == 2 || value == 4, "oai_unet_set_option: sres_mrep must be 2 or 4");
+        OAI_CHECK_ARG(!(h->sres_ring && value != 2), "oai_unet_set_option: the plane ring needs sres_mrep 2");
+        h->sres_mrep = value;
+    } else if (!strcmp(name, "sres_ring")) {           // six-slot z-plane ring (implies sres_mrep 2)
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: sres_ring must be 0 or 1");
+        h->sres_ring = value != 0;
+        if (h->sres_ring) h->sres_mrep = 2;
+    } else if (!strcmp(name, "xcd_group")) {           // logical blocks per XCD deal; 0 = plain launch order
+        OAI_CHECK_ARG(value >= 0 && value <= 4096, "oai_unet_set_option: xcd_group must be in [0, 4096]");
+        h->xcd_group = value;
+    } else {
+        return set_error(OAI_ERR_ARG, "oai_unet_set_option: unknown option '%s'", name);
+    }
+    return OAI_OK;
+}
+
+int oai_unet_range_flag(oai_unet* h, int reset, int* out, void* stream) {
     OAI_CHECK_ARG(h && out, "oai_unet_range_flag: null pointer");
-    OAI_CHECK_HIP(hipMemcpy(out, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));     // synchronises with prior work
-    if (reset && *out) OAI_CHECK_HIP(hipMemset(h->range_flag, 0, sizeof(int)));
+    // ordered on the caller's stream (the one the segment calls were queued on): torch's side streams are non-blocking, so
+    // the null stream would not wait for them and an overflow could be read -- and reset -- before the kernels that set it ran
+    hipStream_t st = (hipStream_t)stream;
+    OAI_CHECK_HIP(hipMemcpyAsync(out, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    OAI_CHECK_HIP(hipStreamSynchronize(st));
+    if (reset && *out) OAI_CHECK_HIP(hipMemsetAsync(h->range_flag, 0, sizeof(int), st));
+    return OAI_OK;
+}
+
+int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream) {
+    OAI_CHECK_ARG(h && dst_dev, "oai_unet_range_flag_snapshot: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    OAI_CHECK_HIP(hipMemcpyAsync(dst_dev, h->range_flag, sizeof(int), hipMemcpyDeviceToDevice, st));
+    OAI_CHECK_HIP(hipMemsetAsync(h->range_flag, 0, sizeof(int), st));
     return OAI_OK;
 }
 
@@ -844,8 +874,7 @@ int oai_segment_tiles(oai_unet* h, const float* vol, int D, int H, int W, const 
     const Plan plan = plan_workspace(h, tile[0], tile[1], tile[2], batch);
     if (plan.total > ws_bytes)
         return set_error(OAI_ERR_WORKSPACE, "oai_segment_tiles: workspace %zu B < %zu B needed for batch %d", ws_bytes, plan.total, batch);
-    const char* notrim = getenv("OAI_NO_TRIM");
-    const bool trimmed = !(notrim && atoi(notrim));
+    const bool trimmed = diag_env("OAI_NO_TRIM", 0) == 0;
     hipStream_t st = (hipStream_t)stream;
     TileSource src{};
     src.vol = vol; src.tiles = nullptr; src.D = D; src.H = H; src.W = W;

@@ -13,6 +13,12 @@ namespace oai {
 // Diagnostic builds only (never shipped: results are wrong): -DOAI_ABLATE=<bits> removes one ingredient of the conv
 // kernels so that its share of the time can be read off (cdna_hip_programming.md 5.4: ablate before optimising).
 //   1 = no halo staging (global loads + LDS writes), 2 = no weight loads, 4 = no LDS fragment reads
+// Runtime timing switches (ConvArgs::dbg / UpArgs::dbg, results wrong when set) likewise exist only under -DOAI_DIAG.
+#ifdef OAI_DIAG
+#define OAI_DBG_BIT(args, bit) (((args).dbg & (bit)) != 0)
+#else
+#define OAI_DBG_BIT(args, bit) false
+#endif
 #ifndef OAI_ABLATE
 #define OAI_ABLATE 0
 #endif

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         __syncthreads();                                 // ... for everybody; and the slots refilled below are read out
                     }
-                    if (ch + 1 < nchunks && !(a.dbg & 1)) {
+                    if (ch + 1 < nchunks && !OAI_DBG_BIT(a, 1)) {
                         if (dz == 0) { issue_plane(ch + 1, 0); issue_plane(ch + 1, 1); }
                         else issue_plane(ch + 1, dz + 1);
                     }
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
-                if (!(a.dbg & 2)) wp += STEP;
+                if (!OAI_DBG_BIT(a, 2)) wp += STEP;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     } else
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                             // every wave is done reading the previous chunk
-        if (!(a.dbg & 1) || ch == 0) stage(ch);
+        if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
         __syncthreads();                                             // ... and everybody else's
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
-            if (!(a.dbg & 2)) wp += STEP;
+            if (!OAI_DBG_BIT(a, 2)) wp += STEP;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         }
                     }
             }
-        } else if (!(a.dbg & 16)) {
+        } else if (!OAI_DBG_BIT(a, 16)) {
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
                 const int sidx = it * 256 + tid, vox = sidx >> 3, q = sidx & 7;
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             }
         }
         if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
-            if (a.pool_out && !(a.dbg & 32)) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
+            if (a.pool_out && !OAI_DBG_BIT(a, 32)) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
                 unsigned char* pb = reinterpret_cast<unsigned char*>(a.pool_out);
                 const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
                 const bool relu = a.relu != 0;
@@ -548,8 +548,8 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage ks landed; the younger stage may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                   // everybody's pieces of stage ks are in; stage ks-1 is read out
-        if (ks + 2 < nks && !(a.dbg & 256)) issue((ks + 2) % 3, ks + 2);
-        if (active && !(a.dbg & 128)) {
+        if (ks + 2 < nks && !OAI_DBG_BIT(a, 256)) issue((ks + 2) % 3, ks + 2);
+        if (active && !OAI_DBG_BIT(a, 128)) {
             const unsigned char* sp = ulds + (ks % 3) * kStage;
             float4 at[2][2], bf[2][4];
 #pragma unroll
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
-            if (active && !(a.dbg & 512)) {
+            if (active && !OAI_DBG_BIT(a, 512)) {
                 unsigned vmask = 0;                                          // which of this lane's 16 voxel rows are real outputs
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             for (int it = 0; it < 16; ++it) {
                 const int vl = it * 4 + (tid >> 6);                          // image row: block voxel (vl >> 5) * 64 + m * 32 + (vl & 31)
                 const unsigned e = vtab[(vl >> 5) * 64 + m * 32 + (vl & 31)];
-                if (qok && e != ~0u && !(a.dbg & 64))
+                if (qok && e != ~0u && !OAI_DBG_BIT(a, 64))
                     *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
             }
         }

@@ -284,6 +284,93 @@ resample_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
     }
 }
 
+// K18 fused into K19, for all maps of a volume at once: the displacement the ITK transform would hold,
+//   disp[zyx][c] = double( (phi[2-c] - identity) * (n - 1) )   (fp32 arithmetic, then widened: exactly phi_to_disp_kernel),
+// is rebuilt from phi's fp32 planes at the 8 corners instead of being read back as 24-byte fp64 triples, and the NM probability
+// maps share one coordinate computation (fp64, same operations in the same order as resample_kernel: bit-identical results).
+// Algorithmic bytes per atlas voxel: NM x (4 read + 4 written) + 12 x (network voxels / atlas voxels) of phi.
+// One lane per atlas voxel, consecutive lanes = consecutive x; blocks are dealt to the 8 XCDs in contiguous z-runs so that a
+// source line of the near-identity map lands in one L2 (as in sample_kernel).
+template <int NM>
+__global__ void __launch_bounds__(kThreads)
+resample_maps_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
+                     const float* __restrict__ phi, int Dn, int Hn, int Wn,
+                     Affine b2n, Affine n2a, float* __restrict__ out, int nzB, int nyB, int nxB, long long nblocks) {
+    const long long per = (nblocks + 7) >> 3;
+    const long long logical = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= per || logical >= nblocks) return;
+    const long long n = (long long)nzB * nyB * nxB;
+    const long long i = logical * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int xb = (int)(i % nxB);
+    const int yb = (int)((i / nxB) % nyB);
+    const int zb = (int)(i / ((long long)nxB * nyB));
+    double nx_, ny_, nz_;
+    apply(b2n, (double)xb, (double)yb, (double)zb, nx_, ny_, nz_);
+    const bool inside = nx_ >= -0.5 && nx_ < Wn - 0.5 && ny_ >= -0.5 && ny_ < Hn - 0.5 && nz_ >= -0.5 && nz_ < Dn - 0.5;
+    if (inside) {
+        int x0, x1, y0, y1, z0, z1;
+        double fx, fy, fz;
+        clamp_split(nx_, Wn, x0, x1, fx);
+        clamp_split(ny_, Hn, y0, y1, fy);
+        clamp_split(nz_, Dn, z0, z1, fz);
+        const long long plane = (long long)Dn * Hn * Wn;
+        const double inz = 1.0 / (Dn - 1), iny = 1.0 / (Hn - 1), inx = 1.0 / (Wn - 1);
+        const int o00 = (z0 * Hn + y0) * Wn, o01 = (z0 * Hn + y1) * Wn, o10 = (z1 * Hn + y0) * Wn, o11 = (z1 * Hn + y1) * Wn;
+        double acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                          // ITK component c (x, y, z) = phi channel 2 - c (w, h, d)
+            const float* p = phi + (long long)(2 - c) * plane;
+            const float sc = (float)((c == 0 ? Wn : c == 1 ? Hn : Dn) - 1);
+            // identity coordinate of the corner along this component's axis: two values per axis
+            const float ia = c == 0 ? identity_coord(x0, inx) : c == 1 ? identity_coord(y0, iny) : identity_coord(z0, inz);
+            const float ib = c == 0 ? identity_coord(x1, inx) : c == 1 ? identity_coord(y1, iny) : identity_coord(z1, inz);
+            auto at = [&](int row, int xx, bool zhi, bool yhi, bool xhi) {
+                const float id = c == 0 ? (xhi ? ib : ia) : c == 1 ? (yhi ? ib : ia) : (zhi ? ib : ia);
+                return (double)((p[row + xx] - id) * sc);
+            };
+            const double c00 = at(o00, x0, 0, 0, 0) * (1 - fx) + at(o00, x1, 0, 0, 1) * fx;
+            const double c01 = at(o01, x0, 0, 1, 0) * (1 - fx) + at(o01, x1, 0, 1, 1) * fx;
+            const double c10 = at(o10, x0, 1, 0, 0) * (1 - fx) + at(o10, x1, 1, 0, 1) * fx;
+            const double c11 = at(o11, x0, 1, 1, 0) * (1 - fx) + at(o11, x1, 1, 1, 1) * fx;
+            acc[c] = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
+        }
+        nx_ += acc[0]; ny_ += acc[1]; nz_ += acc[2];
+    }
+    double ax, ay, az;
+    apply(n2a, nx_, ny_, nz_, ax, ay, az);
+    float r[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) r[m] = 0.0f;
+    if (ax >= -0.5 && ax < nxA - 0.5 && ay >= -0.5 && ay < nyA - 0.5 && az >= -0.5 && az < nzA - 0.5) {
+        int x0, x1, y0, y1, z0, z1;
+        double fx, fy, fz;
+        clamp_split(ax, nxA, x0, x1, fx);
+        clamp_split(ay, nyA, y0, y1, fy);
+        clamp_split(az, nzA, z0, z1, fz);
+        const long long planeA = (long long)nzA * nyA * nxA;
+        const long long o00 = ((long long)z0 * nyA + y0) * nxA, o01 = ((long long)z0 * nyA + y1) * nxA;
+        const long long o10 = ((long long)z1 * nyA + y0) * nxA, o11 = ((long long)z1 * nyA + y1) * nxA;
+        float v[NM][8];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {                           // all loads first: 8 x NM requests in flight per lane
+            const float* p = prob + m * planeA;
+            v[m][0] = p[o00 + x0]; v[m][1] = p[o00 + x1]; v[m][2] = p[o01 + x0]; v[m][3] = p[o01 + x1];
+            v[m][4] = p[o10 + x0]; v[m][5] = p[o10 + x1]; v[m][6] = p[o11 + x0]; v[m][7] = p[o11 + x1];
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const double c00 = (double)v[m][0] * (1 - fx) + (double)v[m][1] * fx;
+            const double c01 = (double)v[m][2] * (1 - fx) + (double)v[m][3] * fx;
+            const double c10 = (double)v[m][4] * (1 - fx) + (double)v[m][5] * fx;
+            const double c11 = (double)v[m][6] * (1 - fx) + (double)v[m][7] * fx;
+            r[m] = (float)((c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) __builtin_nontemporal_store(r[m], out + m * n + i);
+}
+
 inline unsigned grid_for(long long work_items) {
     long long blocks = (work_items + kThreads - 1) / kThreads;
     const long long cap = 256LL * 16;            // 256 CUs x 16 blocks: grid-stride beyond that
@@ -363,6 +450,27 @@ int oai_resample_through_disp(const float* prob, int nzA, int nyA, int nxA, cons
     memcpy(&b, n2a, sizeof(Affine));
     resample_kernel<<<grid_for((long long)nzB * nyB * nxB), kThreads, 0, (hipStream_t)stream>>>(
         prob, nzA, nyA, nxA, disp, Dn, Hn, Wn, a, b, out, nzB, nyB, nxB);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+int oai_resample_maps_through_phi(const float* probs, int n_maps, int nzA, int nyA, int nxA, const float* phi, int Dn, int Hn, int Wn,
+                                  const oai_affine* b2n, const oai_affine* n2a, float* out, int nzB, int nyB, int nxB, void* stream) {
+    OAI_CHECK_ARG(probs && phi && b2n && n2a && out, "oai_resample_maps_through_phi: null pointer");
+    OAI_CHECK_ARG(n_maps >= 1 && n_maps <= 4, "oai_resample_maps_through_phi: 1..4 maps per call");
+    OAI_CHECK_ARG(nzA > 0 && nyA > 0 && nxA > 0 && Dn > 1 && Hn > 1 && Wn > 1 && nzB > 0 && nyB > 0 && nxB > 0,
+                  "oai_resample_maps_through_phi: bad sizes");
+    OAI_CHECK_ARG((long long)Dn * Hn * Wn < (1LL << 31), "oai_resample_maps_through_phi: network grid too large");
+    Affine a, b;
+    memcpy(&a, b2n, sizeof(Affine));
+    memcpy(&b, n2a, sizeof(Affine));
+    const long long nblocks = ((long long)nzB * nyB * nxB + kThreads - 1) / kThreads;
+    OAI_CHECK_ARG(nblocks < (1LL << 31) - 8, "oai_resample_maps_through_phi: output grid too large");
+    const unsigned grid = (unsigned)(((nblocks + 7) / 8) * 8);
+    hipStream_t st = (hipStream_t)stream;
+#define OAI_RS(NM) resample_maps_kernel<NM><<<grid, kThreads, 0, st>>>(probs, nzA, nyA, nxA, phi, Dn, Hn, Wn, a, b, out, nzB, nyB, nxB, nblocks)
+    if (n_maps == 1) OAI_RS(1); else if (n_maps == 2) OAI_RS(2); else if (n_maps == 3) OAI_RS(3); else OAI_RS(4);
+#undef OAI_RS
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }

@@ -112,6 +112,27 @@ def resample_through_disp(prob: torch.Tensor, disp: torch.Tensor, b_index_to_net
     return out
 
 
+def resample_maps_through_phi(maps: torch.Tensor, phi: torch.Tensor, b_index_to_net, net_to_a_index,
+                              out_shape_zyx: Sequence[int]) -> torch.Tensor:
+    """maps [n,zA,yA,xA] (n <= 4) pulled through the dense map phi [3,D,H,W] onto a grid of ``out_shape_zyx``: one launch,
+    bit-identical to ``phi_to_itk_displacement`` + ``resample_through_disp`` per map."""
+    lib = _lib.load()
+    maps = _chk(maps, "maps")
+    phi = _chk(phi, "phi")
+    if maps.dim() != 4 or phi.dim() != 4 or phi.shape[0] != 3:
+        raise ValueError("maps must be [n,z,y,x] and phi [3,D,H,W]")
+    n, nzA, nyA, nxA = maps.shape
+    _, Dn, Hn, Wn = phi.shape
+    nzB, nyB, nxB = (int(v) for v in out_shape_zyx)
+    out = torch.empty((n, nzB, nyB, nxB), dtype=torch.float32, device=maps.device)
+    a1, a2 = make_affine(*b_index_to_net), make_affine(*net_to_a_index)
+    with torch.cuda.device(maps.device):
+        _lib.check(lib.oai_resample_maps_through_phi(maps.data_ptr(), n, nzA, nyA, nxA, phi.data_ptr(), Dn, Hn, Wn,
+                                                     C.byref(a1), C.byref(a2), out.data_ptr(), nzB, nyB, nxB, _stream()),
+                   "oai_resample_maps_through_phi")
+    return out
+
+
 def image_normalize(vol: torch.Tensor, window_min_perc: float = 0.1, window_max_perc: float = 99.9,
                     output_min: float = 0.0, output_max: float = 1.0, return_window: bool = False):
     """``image_normalize`` of oai_analysis/dask_processing.py:10-26 on the device (fp32 image)."""

@@ -10,7 +10,6 @@ Used by bench.py, the cohort driver and the multi-GPU sharding.
 from __future__ import annotations
 
 from dataclasses import dataclass
-import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -33,25 +32,40 @@ class VolumeResult:
     phi: torch.Tensor            # [3,D,H,W] dense map, network grid, [0,1] units
     fc_atlas: torch.Tensor       # FC pulled onto the atlas grid through phi
     tc_atlas: torch.Tensor
+    overflow: Optional[torch.Tensor] = None    # int32[1] on the device: the fp16 range flag of THIS volume's segmentation
+    #                                            (None with exact arithmetic).  Non-zero = the maps are invalid: repeat in fp32.
+    repeated_f32: bool = False   # the fp16x3 run overflowed and these are the results of the fp32 repeat
 
 
 class VolumePipeline:
+    """Range guard of the default fp16x3 arithmetic (|activation| <= 65504): every entry point that returns results either
+    checks the flag of its own volume and repeats that volume in exact fp32 (``check=True``, the default: one stream
+    synchronisation AFTER everything of the volume is queued), or hands the flag snapshot back in ``VolumeResult.overflow`` for a
+    caller that pipelines volumes and checks at download time (``check=False``: CohortRunner, bench.py).  Never silent."""
+
     def __init__(self, unet: UNetEngine, icon: IconEngine, atlas: Image, tile_zyx=TILE_ZYX, overlap_zyx=OVERLAP_ZYX,
                  crop_zyx=CROP_ZYX, batch: Optional[int] = None):
-        # the conv arithmetic is the engine's (UNetEngine(precision=...)); with "fp16x3" callers that keep results
-        # should check unet.range_overflow() once per volume / cohort (Segmenter3DInPatchClassWise does)
         self.unet, self.icon, self.atlas = unet, icon, atlas
         self.tile_zyx, self.overlap_zyx, self.crop_zyx, self.batch = tuple(tile_zyx), tuple(overlap_zyx), tuple(crop_zyx), batch
         self.atlas_dev = torch.from_numpy(np.ascontiguousarray(atlas.array, dtype=np.float32)).to(unet.device)
         self._atlas_net = None
         self._side = None
-        self.overlap_registration = os.environ.get("OAI_OVERLAP_REG", "1") == "1"          # registration underneath the segmentation (+1.5 %)
+        self.overlap_registration = True          # registration underneath the segmentation (+1.5 %); False serialises
 
+    # ---- stages ---------------------------------------------------------------------------------------------------------------
     def segment(self, vol: torch.Tensor, out_mode: int = 0, tile_range: Optional[Tuple[int, int]] = None):
         blocks = self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, tile_range, out_mode, self.batch, self.crop_zyx)
         if tile_range is not None:
             return blocks
         return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
+
+    def _flag_snapshot(self) -> Optional[torch.Tensor]:
+        """Queue (no sync) a copy-and-clear of the fp16 range flag behind the segment calls queued so far."""
+        if self.unet.precision != "fp16x3":
+            return None
+        flag = torch.zeros(1, dtype=torch.int32, device=self.unet.device)
+        self.unet.range_overflow_snapshot(flag)
+        return flag
 
     def register(self, vol: torch.Tensor) -> torch.Tensor:
         """phi_AB with A = patient volume (fixed), B = atlas (moving): registration.py:22-27."""
@@ -60,37 +74,47 @@ class VolumePipeline:
             self._atlas_net = ops.resize_trilinear(self.atlas_dev[None], self.icon.net_shape)[0]
         return self.icon.phi(A, self._atlas_net)
 
-    def resample(self, maps: torch.Tensor, phi: torch.Tensor, meta_A: Image):
-        disp = ops.phi_to_itk_displacement(phi)
+    def resample(self, maps: torch.Tensor, phi: torch.Tensor, meta_A: Image, z_range: Optional[Tuple[int, int]] = None):
+        """Both maps pulled onto the atlas grid through phi (ONE launch reads the displacement once for all maps);
+        ``z_range`` = only atlas slices [z0, z1) (the z-slab shard of SURVEY 8e).  Returns [n_maps, z, y, x]."""
         b2n, n2a = resample_affines(meta_A, self.atlas, self.icon.net_shape)
-        return [ops.resample_through_disp(maps[c], disp, b2n, n2a, self.atlas.array.shape) for c in range(maps.shape[0])]
+        shape = tuple(self.atlas.array.shape)
+        if z_range is not None:
+            z0, z1 = int(z_range[0]), int(z_range[1])
+            if not 0 <= z0 <= z1 <= shape[0]:
+                raise ValueError("z_range outside the atlas grid")
+            A1, b1 = b2n
+            b2n = (A1, b1 + A1[:, 2] * float(z0))          # index_B = index_slab + (0, 0, z0) in ITK's x,y,z order
+            shape = (z1 - z0, shape[1], shape[2])
+        return ops.resample_maps_through_phi(maps, phi, b2n, n2a, shape)
 
-    def segment_sharded(self, vol: torch.Tensor, group=None) -> torch.Tensor:
-        """One volume split over the ranks of ``group`` at tile granularity (SURVEY 8e): every rank runs the U-Net on
-        its contiguous tile range, ONE all_gather (RCCL) gives every rank all kept-centre blocks, then stitch."""
-        from . import parallel
-        _, _, n_tiles = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
-        costs = self.unet.tile_costs(vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)     # border tiles are cheaper: balance the work
-        blocks = parallel.segment_tile_sharded(
-            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx), n_tiles, group, costs)
-        return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
+    # ---- one volume, one GPU --------------------------------------------------------------------------------------------------
+    def run(self, vol: torch.Tensor, meta_A: Image, check: bool = True) -> VolumeResult:
+        res = self._run_overlapped(vol, meta_A) if self.overlap_registration else self._run_serial(vol, meta_A)
+        if check and res.overflow is not None and int(res.overflow.item()):
+            return self.rerun_f32(vol, meta_A)
+        return res
 
-    def run_sharded(self, vol: torch.Tensor, meta_A: Image, group=None) -> VolumeResult:
-        """Single-volume latency mode: segmentation tile-sharded, registration + resample replicated (0.1 TFLOP)."""
-        maps = self.segment_sharded(vol, group)
-        phi = self.register(vol)
-        fc_a, tc_a = self.resample(maps, phi, meta_A)
-        return VolumeResult(maps[0], maps[1], phi, fc_a, tc_a)
+    def rerun_f32(self, vol: torch.Tensor, meta_A: Image, sharded_group="none") -> VolumeResult:
+        """The volume overflowed fp16's range: repeat it with exact fp32 MFMA arithmetic (what Segmenter3DInPatchClassWise does)."""
+        print("WARNING: activation outside fp16 range, repeating the volume in fp32")
+        prev = self.unet.precision
+        self.unet.set_precision("f32")
+        try:
+            res = self.run(vol, meta_A, check=False) if sharded_group == "none" else self.run_sharded(vol, meta_A, sharded_group, check=False)
+        finally:
+            self.unet.set_precision(prev)
+        res.repeated_f32 = True
+        return res
 
-    def run(self, vol: torch.Tensor, meta_A: Image) -> VolumeResult:
-        if self.overlap_registration:
-            return self.run_overlapped(vol, meta_A)
+    def _run_serial(self, vol: torch.Tensor, meta_A: Image) -> VolumeResult:
         maps = self.segment(vol)
+        flag = self._flag_snapshot()
         phi = self.register(vol)
-        fc_a, tc_a = self.resample(maps, phi, meta_A)
-        return VolumeResult(maps[0], maps[1], phi, fc_a, tc_a)
+        atlas_maps = self.resample(maps, phi, meta_A)
+        return VolumeResult(maps[0], maps[1], phi, atlas_maps[0], atlas_maps[1], flag)
 
-    def run_overlapped(self, vol: torch.Tensor, meta_A: Image) -> VolumeResult:
+    def _run_overlapped(self, vol: torch.Tensor, meta_A: Image) -> VolumeResult:
         """Registration needs only the image, not its segmentation: its small, launch- and latency-bound kernels (a few dozen
         workgroups at the deep ICON levels) run on a side stream underneath the segmentation's MFMA kernels; the resample joins."""
         main = torch.cuda.current_stream()
@@ -101,6 +125,40 @@ class VolumePipeline:
             phi = self.register(vol)
             phi.record_stream(main)
         maps = self.segment(vol)
+        flag = self._flag_snapshot()
         main.wait_stream(self._side)
-        fc_a, tc_a = self.resample(maps, phi, meta_A)
-        return VolumeResult(maps[0], maps[1], phi, fc_a, tc_a)
+        atlas_maps = self.resample(maps, phi, meta_A)
+        return VolumeResult(maps[0], maps[1], phi, atlas_maps[0], atlas_maps[1], flag)
+
+    # ---- one volume, all ranks of a group (single-volume latency mode) ---------------------------------------------
+    def segment_sharded(self, vol: torch.Tensor, group=None) -> torch.Tensor:
+        """One volume split over the ranks of ``group`` at tile granularity (SURVEY 8e): every rank runs the U-Net on
+        its contiguous tile range, ONE all_gather (RCCL) gives every rank all kept-centre blocks, then stitch."""
+        from . import parallel
+        _, _, n_tiles = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
+        costs = self.unet.tile_costs(vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)     # border tiles are cheaper: balance the work
+        blocks = parallel.segment_tile_sharded(
+            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx), n_tiles, group, costs)
+        return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
+
+    def run_sharded(self, vol: Optional[torch.Tensor], meta_A: Image, group=None, src: int = 0, check: bool = True) -> VolumeResult:
+        """``vol`` is needed on rank ``src`` only (others may pass None): broadcast -> tile-sharded segmentation + all_gather ->
+        registration replicated (0.1 TFLOP: cheaper than communicating) -> both resamples sharded by atlas z-slab + all_gather.
+        The fp16 range flag is all_reduce(MAX)ed: either every rank keeps the result or every rank repeats in fp32."""
+        from . import parallel
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        vol = parallel.broadcast_volume(vol, meta_A.array.shape, self.unet.device, src, group)
+        maps = self.segment_sharded(vol, group)
+        flag = self._flag_snapshot()
+        if flag is not None:
+            parallel.any_rank(flag, group)
+        phi = self.register(vol)
+        nz = self.atlas.array.shape[0]
+        local = self.resample(maps, phi, meta_A, parallel.slab_range_for_rank(nz, rank, world))
+        atlas_maps = parallel.gather_slabs(local, nz, group)
+        res = VolumeResult(maps[0], maps[1], phi, atlas_maps[0], atlas_maps[1], flag)
+        if check and flag is not None and int(flag.item()):
+            return self.rerun_f32(vol, meta_A, sharded_group=group)
+        return res

@@ -122,13 +122,27 @@ class UNetEngine:
             n = (n + 1) // 2
         return n
 
+    def set_option(self, name: str, value: int) -> None:
+        """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group": include/oai_hip.h)."""
+        _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
+
     def range_overflow(self, reset: bool = True) -> bool:
         """fp16x3 only: True if an activation left fp16's range since the last reset (that run must be repeated in
-        "f32" / "bf16x6").  Synchronises."""
+        "f32" / "bf16x6").  Ordered on the current stream of this engine's device; synchronises that stream."""
         out = C.c_int(0)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.oai_unet_range_flag(self._h, int(reset), C.byref(out)), "oai_unet_range_flag")
+            _lib.check(self.lib.oai_unet_range_flag(self._h, int(reset), C.byref(out), torch.cuda.current_stream().cuda_stream),
+                       "oai_unet_range_flag")
         return bool(out.value)
+
+    def range_overflow_snapshot(self, dst: torch.Tensor) -> None:
+        """Queue (current stream, no sync) a copy of the fp16 range flag into the int32 device tensor ``dst[0]`` and clear it:
+        the flag of the segment calls queued so far, read later together with their results (cohort.py)."""
+        if dst.dtype != torch.int32 or dst.device != self.device or dst.numel() < 1:
+            raise ValueError("dst must be an int32 tensor on the engine's device")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_range_flag_snapshot(self._h, dst.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "oai_unet_range_flag_snapshot")
 
     def tile_flops(self, tile_zyx, overlap_zyx, trimmed: bool) -> float:
         return float(self.lib.oai_unet_tile_flops(self._h, *[int(v) for v in tile_zyx], _lib.int3(overlap_zyx), int(trimmed)))
@@ -151,7 +165,7 @@ class UNetEngine:
             raise ValueError("tiles must be [B,1,D,H,W]")
         tiles = tiles.to(self.device, torch.float32).contiguous()
         B, _, d, h, w = tiles.shape
-        ws = self._workspace((d, h, w), min(B, batch or B))
+        ws = self._workspace((d, h, w), min(B, batch or self.auto_batch((d, h, w), B)))      # the C side loops over what the workspace holds
         out = torch.empty((B, self.n_classes, d, h, w), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_unet_forward_tiles(self._h, tiles.data_ptr(), out.data_ptr(), B, d, h, w,

@@ -97,3 +97,63 @@ def test_tile_shard_gather_matches_single_process(tmp_path, world, weighted, mon
     fc = oseg.assemble(np.pad(got[:, 0], ((0, 0), (o[0], o[0]), (o[1], o[1]), (o[2], o[2]))), g, crop_size_xyz=(4, 4, 2))
     fc_ref, _ = oseg.segment(vol, sd, (16, 16, 8), (4, 4, 2))
     np.testing.assert_allclose(fc, fc_ref, rtol=0, atol=1e-6)
+
+
+def _worker_dist(rank, world, port, out_dir):
+    """broadcast_volume / any_rank / gather_slabs of the tile-shard mode on CPU tensors over gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shape, nz = (6, 10, 12), 11
+    src = torch.arange(6 * 10 * 12, dtype=torch.float32).reshape(shape) * 0.5
+    vol = parallel.broadcast_volume(src if rank == 0 else None, shape, "cpu", 0)
+    ok = torch.equal(vol, src)
+    try:                                                        # the source rank must hold the announced shape
+        if rank == 0:
+            parallel.broadcast_volume(None, shape, "cpu", 0)
+            ok = False
+    except ValueError:
+        pass
+    flag = parallel.any_rank(torch.tensor([1 if rank == world - 1 else 0], dtype=torch.int32))
+    ok = ok and int(flag) == 1
+    ok = ok and int(parallel.any_rank(torch.zeros(1, dtype=torch.int32))) == 0
+    b, e = parallel.slab_range_for_rank(nz, rank, world)
+    full = torch.arange(2 * nz * 3 * 4, dtype=torch.float32).reshape(2, nz, 3, 4)
+    got = parallel.gather_slabs(full[:, b:e].contiguous(), nz)
+    ok = ok and torch.equal(got, full)
+    try:
+        parallel.gather_slabs(full[:, b:e + 1].contiguous() if e < nz else full[:, b - 1:e].contiguous(), nz)
+        ok = False
+    except ValueError:
+        pass
+    with open(os.path.join(out_dir, f"ok_{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_broadcast_flag_agreement_and_slab_gather(tmp_path, world):
+    assert [parallel.slab_range_for_rank(160, r, 8) for r in (0, 7)] == [(0, 20), (140, 160)]
+    mp.spawn(_worker_dist, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok_{r}").read_text() == "1" for r in range(world))
+
+
+@pytest.mark.parametrize("mode", ["tileshard", "replicas"])
+def test_bench_spawns_its_own_ranks(mode):
+    """`python bench.py --gpus 2` with no launcher around it must start its ranks itself: exercised with --dry-run
+    (CPU tensors over gloo, the product's parallel.py, no kernels)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--mode", mode, "--steps", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world_size"] == 2 and out["backend"] == "gloo" and out["dry_run"] and out["mode"] == mode and out["value"] is None
+    # without GPUs a real multi-GPU run must exit non-zero cleanly, before touching a device
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    if not torch.cuda.is_available():
+        assert r.returncode == 2 and "requested" in r.stderr

@@ -1,0 +1,99 @@
+"""GPU: VolumePipeline / CohortRunner -- the fp16 range guard on every entry point, the fused two-map resample
+(bit-identical to the separate displacement + per-map resample), the z-slab form of it, and BASELINE config 4 at size
+(8 full-size volumes streamed through one GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oai_analysis_2_amd.image import Image
+from oai_analysis_2_amd.synth import make_icon_state_dict, make_unet_state_dict, make_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_pipe(unet_sd, precision="fp16x3"):
+    from oai_analysis_2_amd.pipeline import VolumePipeline
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    shape, net = (24, 72, 72), (40, 48, 48)
+    atlas = Image(make_volume(10, shape), [0.4, 0.35, 0.75], [0.0, -1.0, 2.0])
+    pipe = VolumePipeline(UNetEngine(unet_sd, precision=precision), IconEngine(make_icon_state_dict(1, last_scale=0.1), net_shape=net), atlas,
+                          tile_zyx=(16, 32, 32), overlap_zyx=(4, 8, 8), crop_zyx=(4, 8, 8), batch=8)
+    return pipe, shape
+
+
+def test_fused_two_map_resample_is_bit_identical_to_the_separate_path():
+    from oai_analysis_2_amd import ops
+    from oai_analysis_2_amd.registration import resample_affines
+    pipe, shape = _small_pipe(make_unet_state_dict(1, width_div=2))
+    vol = make_volume(9, shape)
+    meta = Image(vol, [0.36, 0.37, 0.7], [1.0, 2.0, 3.0])
+    res = pipe.run(torch.from_numpy(vol).cuda(), meta)
+    disp = ops.phi_to_itk_displacement(res.phi)
+    b2n, n2a = resample_affines(meta, pipe.atlas, pipe.icon.net_shape)
+    for got, src in ((res.fc_atlas, res.fc), (res.tc_atlas, res.tc)):
+        sep = ops.resample_through_disp(src, disp, b2n, n2a, pipe.atlas.array.shape)
+        assert torch.equal(got, sep)
+    # z-slab shards tile the same result
+    maps = torch.stack([res.fc, res.tc])
+    nz = pipe.atlas.array.shape[0]
+    parts = [pipe.resample(maps, res.phi, meta, (z0, z1)) for z0, z1 in ((0, 7), (7, 8), (8, nz))]
+    assert torch.equal(torch.cat(parts, 1), torch.stack([res.fc_atlas, res.tc_atlas]))
+    with pytest.raises(ValueError):
+        pipe.resample(maps, res.phi, meta, (5, nz + 1))
+
+
+def test_pipeline_and_cohort_repeat_an_overflowing_volume_in_fp32():
+    """Weights that push ec0 beyond 65504: fp16x3 must never return garbage -- run() repeats in fp32, run(check=False) hands
+    the flag back, CohortRunner repeats at download time; results equal the fp32 engine's."""
+    from oai_analysis_2_amd.cohort import CohortRunner
+    sd = make_unet_state_dict(seed=7, width_div=2)
+    big = {k: (v * 1e6 if k == "ec0.0.weight" else v) for k, v in sd.items()}
+    pipe, shape = _small_pipe(big, "fp16x3")
+    ref_pipe, _ = _small_pipe(big, "f32")
+    vols = [make_volume(20 + i, shape) for i in range(3)]
+    meta = Image(vols[0], [0.36, 0.37, 0.7], [1.0, 2.0, 3.0])
+    v = torch.from_numpy(vols[0]).cuda()
+    ref = ref_pipe.run(v, meta)
+    assert ref.overflow is None and not ref.repeated_f32
+    raw = pipe.run(v, meta, check=False)
+    assert int(raw.overflow.item()) == 1
+    res = pipe.run(v, meta)
+    assert res.repeated_f32 and pipe.unet.precision == "fp16x3"
+    assert torch.equal(res.fc, ref.fc) and torch.equal(res.tc_atlas, ref.tc_atlas)
+    assert not pipe.unet.range_overflow()                                   # the snapshot cleared the flag
+    for keep in (False, True):
+        got = dict(CohortRunner(pipe, keep_on_device=keep).run([Image(a, meta.spacing, meta.origin) for a in vols]))
+        assert sorted(got) == [0, 1, 2] and all(r.repeated_f32 for r in got.values())
+        assert torch.equal(got[0].fc.cpu(), ref.fc.cpu()) and torch.isfinite(got[2].fc_atlas).all()
+    # and a healthy network is not repeated
+    ok_pipe, _ = _small_pipe(sd, "fp16x3")
+    r = ok_pipe.run(v, meta)
+    assert not r.repeated_f32 and int(r.overflow.item()) == 0
+
+
+def test_cohort_of_8_full_size_volumes_streams_and_matches_single_runs():
+    """BASELINE config 4: 8 synthetic 384x384x160 volumes streamed from host memory through one GPU (upload of i+1 and download of
+    i-1 overlap the compute of i).  Every volume's results equal a plain pipe.run of that volume; frame / range properties hold."""
+    from oai_analysis_2_amd.cohort import CohortRunner
+    from oai_analysis_2_amd.pipeline import VolumePipeline
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    shape = (160, 384, 384)
+    atlas = Image(make_volume(1000, shape), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
+    pipe = VolumePipeline(UNetEngine(make_unet_state_dict(0), precision="fp16x3"), IconEngine(make_icon_state_dict(0, last_scale=0.1)), atlas)
+    imgs = [Image(make_volume(i, shape), [0.36, 0.36, 0.7], [2.0, -3.0, 1.0]) for i in range(8)]
+    seen = []
+    for i, r in CohortRunner(pipe).run(imgs):
+        seen.append(i)
+        assert not r.repeated_f32
+        for m in (r.fc, r.tc):
+            m = m.numpy()
+            assert m[:8].max() == 0 and m[-8:].max() == 0 and m[:, :16].max() == 0 and m[:, :, -16:].max() == 0
+            assert 0 < m[8:-8, 16:-16, 16:-16].min() and m.max() < 1
+        assert r.fc_atlas.shape == shape and torch.isfinite(r.fc_atlas).all() and r.phi.shape == (3, 80, 192, 192)
+        if i in (0, 3, 7):                                                   # single-run equality on three of the eight
+            one = pipe.run(torch.from_numpy(imgs[i].array).cuda(), imgs[i])
+            for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
+                assert torch.equal(getattr(one, name).cpu(), getattr(r, name)), (i, name)
+    assert seen == list(range(8))

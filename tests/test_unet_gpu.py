@@ -211,8 +211,8 @@ def test_fp16x3_reports_activations_outside_fp16_range():
     assert _rel(eng2.forward_tiles(x).cpu().numpy(), ref) < REL                        # the exact mode is unaffected
 
 
-@pytest.mark.parametrize("env", [{"OAI_SRES_MREP": "2"}, {"OAI_SRES_RING": "1"}, {"OAI_XCD_GROUP": "0"}, {"OAI_XCD_GROUP": "7"}, {"OAI_SRES": "0"}])
-def test_split_fp16_kernel_variants_agree(golden_dir, env, monkeypatch):
+@pytest.mark.parametrize("opts", [{"sres_mrep": 2}, {"sres_ring": 1}, {"xcd_group": 0}, {"xcd_group": 7}, {"sres": 0}])
+def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     """The tuning variants of the default path (2 z slices per block, the six-slot plane ring, other XCD dealings, fp32-resident
     activations) accumulate in the same k order: identical stitched maps, and the golden tolerance of the default."""
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
@@ -222,17 +222,45 @@ def test_split_fp16_kernel_variants_agree(golden_dir, env, monkeypatch):
     tile_zyx, ovl_zyx, crop_zyx = patch[::-1], ovl[::-1], (ovl[2], ovl[0], ovl[1])
     sd = make_unet_state_dict(seed=int(z["weight_seed"]))
 
-    def run():
-        eng = UNetEngine(sd, precision="fp16x3")                  # the variant switches are read when the precision is set
+    def run(options=()):
+        eng = UNetEngine(sd, precision="fp16x3")
+        for k, v in dict(options).items():                        # explicit options on the handle: the library reads no environment
+            eng.set_option(k, v)
         return eng.stitch(eng.segment_tiles(vol, tile_zyx, ovl_zyx, out_mode=0, batch=9, crop_zyx=crop_zyx), vol.shape, tile_zyx, ovl_zyx, crop_zyx).cpu().numpy()
 
     base = run()
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    got = run()
-    if "OAI_SRES" in env:                                          # other activation format: same arithmetic, other rounding points
+    got = run(opts)
+    if "sres" in opts:                                              # other activation format: same arithmetic, other rounding points
         assert np.abs(got - base).max() < 1e-5
     else:
         assert np.array_equal(got, base)
     budget = 12.0 * vol.numel() / 23592960
     assert np.abs(got[0].astype(np.float64) - z["fc_prob"]).sum() < budget
+
+
+@pytest.mark.parametrize("precision", ["f32", "fp16x3"])
+def test_mask_is_the_fp32_sigmoid_predicate_not_the_sign_test(precision):
+    """`sigmoid(x) > 0.5` and `x > 0` DIFFER for 0 < x <= ~8.94e-8 (fp32 sigmoid rounds to exactly 0.5).
+    A head whose logits all fall within a few 1e-7 of zero populates that window densely; the mask output (out_mode 1, fused head on the default
+    path) must equal torch's own `torch.sigmoid(logits) > 0.5` -- the reference's expression, segmenter.py:121-124 -- voxel for voxel."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = make_unet_state_dict(seed=6, width_div=2)
+    sd = dict(sd)
+    sd["dc0.weight"] = sd["dc0.weight"] * 2e-7
+    sd["dc0.bias"] = torch.tensor([4e-8, -4e-8])
+    eng = UNetEngine(sd, precision=precision)
+    shape, tile, ovl = (24, 72, 72), (16, 32, 32), (4, 8, 8)
+    vol = torch.from_numpy(make_volume(3, shape)).cuda()
+    out = {m: eng.stitch(eng.segment_tiles(vol, tile, ovl, out_mode=m, crop_zyx=ovl), shape, tile, ovl, ovl).cpu()
+           for m in (0, 1, 2)}
+    inner = (slice(None), slice(4, -4), slice(8, -8), slice(8, -8))
+    logits, prob, mask = out[2][inner], out[0][inner], out[1][inner]
+    window = ((logits > 0) & (logits <= 8.94e-8)).sum().item()
+    assert window > 1000, "the test must populate the D-4 window"
+    ref_prob = torch.sigmoid(logits)
+    assert torch.equal(prob, ref_prob)
+    assert torch.equal(mask > 0.5, ref_prob > 0.5)
+    disagree = ((logits > 0) != (ref_prob > 0.5)).sum().item()
+    print(f"[D-4 {precision}] {window} logits in (0, 8.94e-8]; sign test and sigmoid predicate disagree on {disagree} voxels")
+    assert disagree >= window // 2            # the sign test would be wrong on (most of) the window
+    assert (mask > 0.5).any() and not (mask > 0.5).all()
