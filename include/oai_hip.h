@@ -68,6 +68,18 @@ int oai_resize_trilinear(const float* in_dev, int C, int d, int h, int w,
  * network-voxel units) = reverse_components((phi - identity) * (shape - 1)). */
 int oai_phi_to_itk_displacement(const float* phi_dev, int D, int H, int W, double* disp_dev, void* stream);
 
+/* A whole compose chain of icon_registration's TwoStepRegistration / DownsampleRegistration closures per output voxel, without
+ * materialising the intermediate maps (SURVEY.md K15 "fuse chains", K18):
+ *     c = identity(D,H,W) [+ start_dev]        start_dev [3][D][H][W] may be NULL (the package's isIdentity shortcut when given)
+ *     c = c + sample(fields[i], c)             i = 0 .. n_fields-1 (n_fields <= 2), fields[i] is [3][fd][fh][fw] with
+ *                                              (fd,fh,fw) = field_dims_zyx[3i..3i+2] -- usually the half-resolution grid
+ *     out = image_dev ? sample(image_dev [id][ih][iw], c)  ->  out_dev [D][H][W]
+ *                     : c                                   ->  out_dev [3][D][H][W]
+ * `sample` is oai_grid_sample3d's (grid_sample bilinear / border / align_corners=True on [0,1] coordinates).  Bit-identical to
+ * the sequence of oai_compose / oai_grid_sample3d calls it replaces.  `fields` and `field_dims_zyx` are HOST arrays. */
+int oai_warp_chain(const float* start_dev, int D, int H, int W, int n_fields, const float* const* fields,
+                   const int* field_dims_zyx, const float* image_dev, int id, int ih, int iw, float* out_dev, void* stream);
+
 /* Geometry of one image for the resample: index_xyz -> physical = A*idx + b (row-major 3x3 + 3). */
 typedef struct oai_affine { double A[9]; double b[3]; } oai_affine;
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "oai_phi_to_itk_displacement": (_I, [_P, _I, _I, _I, _P, _P]),
     "oai_resample_through_disp": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
                                        _P, _I, _I, _I, _P]),
+    "oai_warp_chain": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_I), _P, _I, _I, _I, _P, _P]),
     "oai_resample_maps_through_phi": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(Affine), C.POINTER(Affine),
                                            _P, _I, _I, _I, _P]),
     "oai_unet_tile_costs": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),

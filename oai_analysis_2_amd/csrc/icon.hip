@@ -335,7 +335,7 @@ Ws plan_ws(int D, int H, int W, char* base) {
     auto take = [&](size_t floats) { float* p = (float*)(base + o); o += align256(floats * 4); return p; };
     Ws s;
     s.a = take(vl); s.b = take(vl); s.d1 = take(3 * vl); s.d2 = take(3 * vl); s.aw = take(vl);
-    s.d3 = take(3 * vh); s.c1 = take(3 * vh); s.c2 = take(3 * vh); s.Aw = take(vh);
+    s.d3 = take(3 * vh); s.c1 = nullptr; s.c2 = nullptr; s.Aw = take(vh);     // (c1, c2: never materialised since the chains are fused)
     s.unet = take(unet_ws_floats(D, H, W));
     s.total_bytes = o;
     return s;
@@ -416,16 +416,17 @@ int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, vo
     RUN(oai_avgpool2_3d(A, 1, D, H, W, s.a, st));                                  // DownsampleRegistration.forward
     RUN(oai_avgpool2_3d(B, 1, D, H, W, s.b, st));
     RUN(unet_forward(h->net[0], s.a, s.b, d, hh, w, s.d1, s.unet, st));            // FFVF(u1)
-    RUN(oai_compose(s.d1, d, hh, w, nullptr, d, hh, w, 1, s.c1, st));              // id_l + d1 (isIdentity shortcut)
-    RUN(oai_grid_sample3d(s.a, 1, d, hh, w, s.c1, d, hh, w, s.aw, st));            // a warped
+    // the warp / compose closures run as fused chains (oai_warp_chain, warp.hip): bit-identical to the op-by-op sequence of
+    // oai_compose / oai_grid_sample3d calls (tests/test_warp_gpu.py), none of c1..c4 is materialised
+    const float* f21[2] = {s.d2, s.d1};
+    const int low[6] = {d, hh, w, d, hh, w};
+    RUN(oai_warp_chain(s.d1, d, hh, w, 0, nullptr, nullptr, s.a, d, hh, w, s.aw, st));        // a warped by id_l + d1 (isIdentity shortcut)
     RUN(unet_forward(h->net[1], s.aw, s.b, d, hh, w, s.d2, s.unet, st));           // FFVF(u2)
-    RUN(oai_compose(s.d2, d, hh, w, nullptr, D, H, W, 0, s.c1, st));               // c1 = id_h + sample(d2, id_h)
-    RUN(oai_compose(s.d1, d, hh, w, s.c1, D, H, W, 0, s.c2, st));                  // c2 = c1 + sample(d1, c1)
-    RUN(oai_grid_sample3d(A, 1, D, H, W, s.c2, D, H, W, s.Aw, st));                // A warped
+    // c1 = id_h + sample(d2, id_h); c2 = c1 + sample(d1, c1); A warped by c2
+    RUN(oai_warp_chain(nullptr, D, H, W, 2, f21, low, A, D, H, W, s.Aw, st));
     RUN(unet_forward(h->net[2], s.Aw, B, D, H, W, s.d3, s.unet, st));              // FFVF(u3)
-    RUN(oai_compose(s.d3, D, H, W, nullptr, D, H, W, 1, s.c1, st));                // c3 = id_h + d3 (shortcut)
-    RUN(oai_compose(s.d2, d, hh, w, s.c1, D, H, W, 0, s.c2, st));                  // c4 = c3 + sample(d2, c3)
-    RUN(oai_compose(s.d1, d, hh, w, s.c2, D, H, W, 0, phi, st));                   // phi = c4 + sample(d1, c4)
+    // c3 = id_h + d3 (shortcut); c4 = c3 + sample(d2, c3); phi = c4 + sample(d1, c4)
+    RUN(oai_warp_chain(s.d3, D, H, W, 2, f21, low, nullptr, 0, 0, 0, phi, st));
 #undef RUN
     return OAI_OK;
 }

@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "unet_kernels.h"
 
 namespace oai {
@@ -150,9 +152,14 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     const unsigned char* s0 = reinterpret_cast<const unsigned char*>(a.src0) + srec(tile, nch0, plane, 0, 0);
     const unsigned char* s1 = reinterpret_cast<const unsigned char*>(a.src1) + srec(tile, nch1, plane, 0, 0);
 
-    // ---- staging plan, once per workgroup: for each of this thread's NIT slots, the voxel it belongs to (-1 = outside the
-    // tile, i.e. Conv3d's zero padding, or beyond the halo box -> the zero record) and the logical slot it fetches
-    int pv[NIT];                     // (voxel index << 2) | swizzle key, or -1
+    // ---- staging plan, once per workgroup: for each of this thread's NIT slots, the 32-bit BYTE OFFSET inside one chunk plane of
+    // the 16-byte slot it fetches (record of the voxel + swizzled slot), or kNoPiece = outside the tile (Conv3d's zero padding) or
+    // beyond the halo box -> the zero record.  One VGPR per piece and four VALU per piece and chunk; the first version kept
+    // (voxel << 2 | key) and rebuilt a 64-bit address with a 64-bit multiply-add per piece, which the register allocator answered
+    // with ten 8-byte scratch spills RELOADED INSIDE the chunk loop, each behind an `s_waitcnt vmcnt(0)` that also drained the
+    // DMA pieces already in flight (the staging of a chunk was serialised, one L2 round trip per piece).
+    constexpr unsigned kNoPiece = 0xFFFFFFFFu;
+    unsigned poff[NIT];
     const int pslot = tid & 3;       // LDS slot position of this thread's pieces (P = it*256 + tid, so P & 3 = tid & 3)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -160,15 +167,14 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         const int hx = r % HX, t2 = r / HX, hy = t2 % HY, hz = t2 / HY;
         const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
         const bool ok = r < HVOX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        pv[it] = ok ? ((((gz * a.H + gy) * a.W + gx) << 2) | ((hx >> 2) & 3)) : -1;
+        poff[it] = ok ? ((unsigned)((gz * a.H + gy) * a.W + gx) << 6) | (unsigned)((pslot ^ ((hx >> 2) & 3)) << 4) : kNoPiece;
     }
-    auto stage = [&](int ch) {
+    auto stage = [&](int ch) __attribute__((always_inline)) {
         const bool first = ch < nch0;
-        const unsigned char* sb = first ? s0 : s1;
-        const int c = first ? ch : ch - nch0;
+        const unsigned char* cb = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const unsigned char* g = pv[it] >= 0 ? sb + ((size_t)c * plane + (size_t)(pv[it] >> 2)) * 64 + ((pslot ^ (pv[it] & 3)) << 4) : zero_rec;
+            const unsigned char* g = poff[it] != kNoPiece ? cb + poff[it] : zero_rec;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds + (it * 256 + wave * 64) * 16), 16, 0, 0);
         }
@@ -220,14 +226,6 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
     float4 acur[2][MREP];           // (a register prefetch of the next tap's A fragments was measured: no gain, and it costs MREP 2 its third workgroup per CU)
-    auto load_a = [&](float4 (&dst)[2][MREP], int t) {
-        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int m = 0; m < MREP; ++m)
-                dst[k][m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
-    };
     if constexpr (RING) {
         const int arel = (ly * HX + lx) * 64;                          // this lane's voxel inside a plane, tap (dy, dx) = (0, 0)
         issue_plane(0, 0); issue_plane(0, 1); issue_plane(0, 2); issue_plane(0, 3);
@@ -278,35 +276,71 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                     for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
             }
         }
-    } else
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();                                             // every wave is done reading the previous chunk
-        if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
-        __syncthreads();                                             // ... and everybody else's
+    } else {
+        // One chunk = 27 taps x 24 MFMAs.  Pass order per tap: a0.b0, a0.b1, a1.b0 -- so the registers of the a0 fragments are dead
+        // after the second pass and those of a1 before the third: the a1 fragments of tap t are read from LDS at the top of the tap
+        // (needed 16 MFMAs = 512 cycles later) and the a0 fragments of tap t+1 behind the second pass (needed 8 MFMAs later): the
+        // LDS latency never meets an MFMA that waits for it, at no extra register (a second set of A registers does not fit).
+        // Blocks whose four z slices are all inside the tile's box (the large majority) run a branch-free stream; the first
+        // version tested `m >= m_lo && m < m_hi` around every pair of MFMAs, which hipcc turned into twelve taken branches per tap
+        // with the MFMA pairs in out-of-line blocks behind `s_waitcnt lgkmcnt(0)`.
+        // ML = number of live z slices of the block (slices [0, ML) are inside the tile's box): a compile-time count, so that the
+        // tap stream is branch-free and the dead slices cost neither LDS reads nor MFMAs.  Blocks whose live slices do not start at
+        // 0 (rare: a border tile's box starting inside a block) run ML = MREP; their dead rows accumulate values that the
+        // epilogue never stores (rows of an MFMA are independent).
+        auto run_chunks = [&](auto ml_tag) __attribute__((always_inline)) {
+            constexpr int ML = decltype(ml_tag)::value;
+            auto load_a = [&](float4 (&dst)[MREP], int t, int k) __attribute__((always_inline)) {
+                const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            load_a(acur, t);                                         // read at the top of the tap (counted lgkmcnt waits)
+                for (int m = 0; m < ML; ++m)
+                    dst[m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
+            };
+            for (int ch = 0; ch < nchunks; ++ch) {
+                __syncthreads();                                             // every wave is done reading the previous chunk
+                if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
+                __syncthreads();                                             // ... and everybody else's
+                load_a(acur[0], 0, 0);
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+                for (int t = 0; t < 27; ++t) {
+                    load_a(acur[1], t, 1);
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
-            if (!OAI_DBG_BIT(a, 2)) wp += STEP;
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+                        for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
+                    if (!OAI_DBG_BIT(a, 2)) wp += STEP;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MREP; ++m) {
-                    if ((OAI_ABLATE & 8) || (m >= m_lo && m < m_hi)) {
+                    for (int p = 0; p < 2; ++p)                              // a0.b0, a0.b1
 #pragma unroll
-                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[PA[p]][m], bcur[PB[p]][n], acc[m][n]);
-                    }
+                        for (int m = 0; m < ML; ++m)
+#pragma unroll
+                            for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[0][m], bcur[p][n], acc[m][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < 27) load_a(acur[0], t + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)                             // a1.b0
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[1][m], bcur[0][n], acc[m][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
                 }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
+            }
+        };
+        const int ml = m_lo == 0 ? m_hi : MREP;                         // workgroup-uniform
+        if constexpr (MREP == 4) {
+            if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
+            else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
+            else if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+            else run_chunks(std::integral_constant<int, 1>{});
+        } else {
+            if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+            else run_chunks(std::integral_constant<int, 1>{});
         }
     }
 

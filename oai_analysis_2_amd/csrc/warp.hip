@@ -132,6 +132,90 @@ sample_kernel(const float* __restrict__ src, int C_rt, int d, int h, int w,
     }
 }
 
+// SURVEY K15 "fuse chains phi(psi(x))" / K18: a whole compose chain per output voxel, in registers:
+//     c  = identity [+ start]                         (start: a displacement on the OUTPUT grid -- the isIdentity shortcut)
+//     c  = c + sample(field_i, c)     i = 0 .. nf-1   (each field on its own, usually half-resolution, grid)
+//     out = WARP ? sample(image, c) : c
+// i.e. TwoStepRegistration / DownsampleRegistration's closures of icon_registration composed without materialising c1..c4.
+// Every sample is gather8 with the arithmetic and order of sample_kernel, and an intermediate map that the unfused launches
+// round to fp32 in memory is the same fp32 value in a register, so the result is bit-identical to the chain of
+// oai_compose / oai_grid_sample3d calls it replaces (tests/test_warp_gpu.py), while the traffic drops from ~25 B per voxel and
+// link to the compulsory 12 B (start) + 12 x (field voxels / output voxels) per field + 12 (or 4 + 4 for WARP) B written.
+struct ChainArgs {
+    const float* start;                  // [3][D][H][W] or nullptr
+    const float* field[2];               // [3][fd][fh][fw]
+    int fd[2], fh[2], fw[2];
+    int nf;
+    const float* image;                  // WARP: [id][ih][iw]
+    int id, ih, iw;
+    float* out;                          // WARP: [D][H][W]; else [3][D][H][W]
+    int D, H, W, nbx, nby, nbz;
+    double inz, iny, inx;
+};
+
+template <bool WARP>
+__global__ void __launch_bounds__(kThreads)
+chain_kernel(const ChainArgs a) {
+    constexpr int U = OAI_WARP_U;
+    const int D = a.D, H = a.H, W = a.W;
+    const int plane_out = D * H * W;
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) & 3, tz = threadIdx.x >> 7;
+    const int nb = a.nbx * a.nby * a.nbz;
+    const int per = (nb + 7) >> 3;
+    const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || logical >= nb) return;
+    const int bx = logical % a.nbx, by = (logical / a.nbx) % a.nby, bz = logical / (a.nbx * a.nby);
+    const int x = bx * 32 + tx, y = by * 4 + ty;
+    int lin[U];
+    bool ok[U];
+    float c[3][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int z = (bz * U + u) * 2 + tz;
+        ok[u] = x < W && y < H && z < D;
+        lin[u] = ok[u] ? (z * H + y) * W + x : 0;
+        c[0][u] = identity_coord(z, a.inz); c[1][u] = identity_coord(y, a.iny); c[2][u] = identity_coord(x, a.inx);
+        if (a.start) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[k][u] = c[k][u] + a.start[k * plane_out + lin[u]];      // add_identity_kernel: id + disp
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i < a.nf) {
+            const int plane = a.fd[i] * a.fh[i] * a.fw[i];
+            Taps t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) make_taps(c[0][u], c[1][u], c[2][u], a.fd[i], a.fh[i], a.fw[i], t[u]);
+            float g[3][U];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[k][u] = gather8(a.field[i] + k * plane, t[u]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u) c[k][u] = g[k][u] + c[k][u];                               // sample_kernel MODE 1: r += coord
+        }
+    }
+    if constexpr (WARP) {
+        Taps t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) make_taps(c[0][u], c[1][u], c[2][u], a.id, a.ih, a.iw, t[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float r = gather8(a.image, t[u]);
+            if (ok[u]) __builtin_nontemporal_store(r, a.out + lin[u]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) __builtin_nontemporal_store(c[k][u], a.out + k * plane_out + lin[u]);
+    }
+}
+
 // out = identity + disp (same grid): the package's isIdentity shortcut
 __global__ void __launch_bounds__(kThreads)
 add_identity_kernel(const float* __restrict__ disp, int D, int H, int W, float* __restrict__ out) {
@@ -415,6 +499,34 @@ int oai_compose(const float* disp, int d, int h, int w, const float* coords, int
         return OAI_OK;
     }
     return launch_sample<1>(disp, 3, d, h, w, coords, D, H, W, out, (hipStream_t)stream);
+}
+
+int oai_warp_chain(const float* start, int D, int H, int W, int n_fields, const float* const* fields, const int* field_dims,
+                   const float* image, int id, int ih, int iw, float* out, void* stream) {
+    OAI_CHECK_ARG(out, "oai_warp_chain: null output");
+    OAI_CHECK_ARG(D > 1 && H > 1 && W > 1, "oai_warp_chain: output axes must be > 1");
+    OAI_CHECK_ARG(n_fields >= 0 && n_fields <= 2, "oai_warp_chain: 0..2 fields per call");
+    OAI_CHECK_ARG(n_fields == 0 || (fields && field_dims), "oai_warp_chain: null field list");
+    OAI_CHECK_ARG((long long)3 * D * H * W < (1LL << 31), "oai_warp_chain: output grid too large (32-bit offsets)");
+    ChainArgs a{};
+    a.start = start; a.nf = n_fields;
+    for (int i = 0; i < n_fields; ++i) {
+        OAI_CHECK_ARG(fields[i], "oai_warp_chain: null field");
+        a.field[i] = fields[i];
+        a.fd[i] = field_dims[3 * i]; a.fh[i] = field_dims[3 * i + 1]; a.fw[i] = field_dims[3 * i + 2];
+        OAI_CHECK_ARG(a.fd[i] > 1 && a.fh[i] > 1 && a.fw[i] > 1 && (long long)3 * a.fd[i] * a.fh[i] * a.fw[i] < (1LL << 31), "oai_warp_chain: bad field size");
+    }
+    a.image = image; a.id = id; a.ih = ih; a.iw = iw;
+    if (image) OAI_CHECK_ARG(id > 1 && ih > 1 && iw > 1 && (long long)id * ih * iw < (1LL << 31), "oai_warp_chain: bad image size");
+    a.out = out; a.D = D; a.H = H; a.W = W;
+    a.nbx = (W + 31) / 32; a.nby = (H + 3) / 4; a.nbz = ((D + 1) / 2 + OAI_WARP_U - 1) / OAI_WARP_U;
+    a.inz = 1.0 / (D - 1); a.iny = 1.0 / (H - 1); a.inx = 1.0 / (W - 1);
+    const long long nb = (long long)a.nbx * a.nby * a.nbz;
+    const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
+    if (image) chain_kernel<true><<<grid, kThreads, 0, (hipStream_t)stream>>>(a);
+    else chain_kernel<false><<<grid, kThreads, 0, (hipStream_t)stream>>>(a);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
 }
 
 int oai_avgpool2_3d(const float* in, int C, int D, int H, int W, float* out, void* stream) {

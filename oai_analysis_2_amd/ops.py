@@ -60,6 +60,34 @@ def compose(disp: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optio
     return out
 
 
+def warp_chain(out_shape: Sequence[int], fields: Sequence[torch.Tensor] = (), start: Optional[torch.Tensor] = None,
+               image: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """c = identity(out_shape) [+ start]; c = c + sample(f, c) for f in fields (<= 2); returns sample(image, c) [D,H,W] when an
+    image [d,h,w] is given, else c [3,D,H,W].  One launch, bit-identical to the compose / grid_sample3d calls it replaces."""
+    lib = _lib.load()
+    D, H, W = (int(v) for v in out_shape)
+    fields = [_chk(f, "field") for f in fields]
+    if len(fields) > 2 or any(f.dim() != 4 or f.shape[0] != 3 for f in fields):
+        raise ValueError("at most two fields, each [3,d,h,w]")
+    dev = (fields[0] if fields else start if start is not None else image).device
+    if start is not None:
+        start = _chk(start, "start")
+        if tuple(start.shape) != (3, D, H, W):
+            raise ValueError("start must be [3,D,H,W] on the output grid")
+    if image is not None:
+        image = _chk(image, "image")
+        if image.dim() != 3:
+            raise ValueError("image must be [d,h,w]")
+    ptrs = (C.c_void_p * max(1, len(fields)))(*[f.data_ptr() for f in fields])
+    dims = (C.c_int * max(3, 3 * len(fields)))(*[int(v) for f in fields for v in f.shape[1:]])
+    out = torch.empty((D, H, W) if image is not None else (3, D, H, W), dtype=torch.float32, device=dev)
+    idims = tuple(image.shape) if image is not None else (0, 0, 0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.oai_warp_chain(start.data_ptr() if start is not None else None, D, H, W, len(fields), ptrs, dims,
+                                      image.data_ptr() if image is not None else None, *idims, out.data_ptr(), _stream()), "oai_warp_chain")
+    return out
+
+
 def avgpool2(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _chk(x, "x")

@@ -96,3 +96,38 @@ def test_phi_to_displacement_and_resample():
     got = ops.resample_through_disp(_dev(A.array), got_disp, b2n, n2a, B.array.shape).cpu().numpy()
     assert (ref == 0).any() and (ref != 0).any()      # exercises the outside-buffer default pixel
     assert np.abs(got - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(20, 44, 36), (17, 33, 29), (80, 192, 192)])
+def test_fused_warp_chain_is_bit_identical_to_the_op_by_op_closures(shape):
+    """oai_warp_chain (SURVEY K15 "fuse chains", K18) against the sequence of compose / grid_sample3d launches it replaces in
+    oai_icon_forward -- the three chains of regis_net_direction (oracle/icon.py) -- and against the oracle's torch ops."""
+    from oai_analysis_2_amd import ops
+    low = tuple((s + 1) // 2 for s in shape)
+    d1, d2 = _dev(make_smooth_field(1, low, 0.03)), _dev(make_smooth_field(2, low, 0.02))
+    d3 = _dev(make_smooth_field(3, shape, 0.02))
+    A, a = _dev(make_volume(4, shape)), _dev(make_volume(5, low))
+    # low-resolution warp through the isIdentity shortcut: a(id_l + d1)
+    c_l = ops.compose(d1, None, shortcut=True)
+    assert torch.equal(ops.warp_chain(low, start=d1, image=a), ops.grid_sample3d(a[None], c_l)[0])
+    # A(c2), c2 = c1 + d1(c1), c1 = id_h + d2(id_h)
+    c1 = ops.compose(d2, None, out_shape=shape, shortcut=False)
+    c2 = ops.compose(d1, c1)
+    got = ops.warp_chain(shape, fields=[d2, d1], image=A)
+    assert torch.equal(got, ops.grid_sample3d(A[None], c2)[0])
+    assert torch.equal(ops.warp_chain(shape, fields=[d2, d1]), c2) and torch.equal(ops.warp_chain(shape, fields=[d2]), c1)
+    # phi = c4 + d1(c4), c4 = c3 + d2(c3), c3 = id_h + d3
+    c3 = ops.compose(d3, None, shortcut=True)
+    phi = ops.compose(d1, ops.compose(d2, c3))
+    assert torch.equal(ops.warp_chain(shape, fields=[d2, d1], start=d3), phi)
+    assert torch.equal(ops.warp_chain(shape, start=d3), c3)
+    # and the oracle (torch CPU ops of the restated package)
+    id_h = oicon.identity_map(shape)
+    t = lambda x: x.cpu()[None]
+    r3 = id_h + t(d3)
+    r4 = r3 + oicon.sample_at(t(d2), r3)
+    ref = (r4 + oicon.sample_at(t(d1), r4))[0].numpy()
+    ident = id_h[0].numpy()
+    assert _rel(phi.cpu().numpy() - ident, ref - ident) < TOL
+    with pytest.raises(Exception):
+        ops.warp_chain(shape, fields=[d2, d1, d2])
