@@ -233,6 +233,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in exact fp32 MFMA (full --steps) reported beside the primary")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="result-preserving tuning option of the fp16x3 path (oai_unet_set_option: sres, sres_mrep, sres_ring, xcd_group); repeatable")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of launcher + collectives, no GPU, no kernels")
     args = ap.parse_args()
 
@@ -276,6 +278,9 @@ def main():
     unet_sd = make_unet_state_dict(0)
     icon_sd = make_icon_state_dict(0, last_scale=0.1)
     unet = UNetEngine(unet_sd, precision=args.precision)
+    for opt in args.option:
+        name, _, value = opt.partition("=")
+        unet.set_option(name, int(value))
     icon = IconEngine(icon_sd)
     atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
     pipe = VolumePipeline(unet, icon, atlas, batch=args.batch or None)
@@ -347,7 +352,8 @@ def main():
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": getattr(unet, "last_batch", args.batch), "parallelism": f"{args.mode} x{world}",
-                       "collective_backend": ("nccl (RCCL)" if use_dist else None), "world_size": world},
+                       "collective_backend": ("nccl (RCCL)" if use_dist else None), "world_size": world,
+                       "options": args.option or None},
             "roofline": roofline(args.precision, conv_ms, conv_launches, args.steps, my_frac),
             "fp16_range_overflow": overflow,
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,

@@ -1,21 +1,26 @@
 #!/bin/bash
 # Round profile: (1) rocprofv3 kernel trace + stats of the default bench command, (2) HBM-side traffic counters of the
-# split-resident segmentation kernels in their own passes (counters + kernel-trace only).
+# split-resident segmentation kernels in their own passes (counters + kernel-trace only), (3) SQ / GRBM counters of the dominant
+# kernel (MFMA-busy share, effective clock = GRBM_GUI_ACTIVE / 8 / wall).   usage: bash scripts/prof_round.sh [round tag]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; O=$R/gpurun_out/round_$TAG; mkdir -p $O; cd $R
 rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 > $O/bench_line.json 2> $O/bench.err
-tail -1 $O/bench_line.json | head -c 3000; echo
+tail -1 $O/bench_line.json | head -c 1500; echo
 export PREC=fp16x3
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python3 scripts/perf_layers.py > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python3 scripts/perf_layers.py > $O/write.log 2>&1
-python3 - <<'PY'
-import csv, os, json
-O = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/round"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/sq -o s --output-format csv -- python3 scripts/perf_layers.py > $O/sq.log 2>&1
+python3 - "$O" <<'PY'
+import csv, os, json, sys, glob, collections
+O = sys.argv[1]
+def find(d, suffix):
+    fs = glob.glob(os.path.join(O, d, "**", "*" + suffix), recursive=True)
+    return fs[0] if fs else None
 def load(path, name):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
-f = load(O + "/fetch/f_counter_collection.csv", "FETCH_SIZE"); w = load(O + "/write/w_counter_collection.csv", "WRITE_SIZE")
+f = load(find("fetch", "counter_collection.csv"), "FETCH_SIZE"); w = load(find("write", "counter_collection.csv"), "WRITE_SIZE")
 def warm(rows):                                       # second (warm) 32-tile pass = from the last first-conv launch on
     i = max(k for k, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"])
     return rows[i:]
@@ -34,4 +39,23 @@ js = {"kernel": "conv3_igemm_sres (all tile shapes)", "bytes_per_launch": (tot["
       "launches_per_32_tile_pass": tot["conv_n"], "all_kernels_fetch_x2_bytes": tot["all_f"] * 2**20, "all_kernels_write_bytes": tot["all_w"] * 2**20}
 json.dump(js, open(O + "/traffic_sres.json", "w"), indent=1)
 print(json.dumps(js))
+# SQ / GRBM sums per kernel + the kernel-trace durations of the same pass -> MFMA-busy share and effective clock
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(find("sq", "counter_collection.csv"))):
+    agg[r["Kernel_Name"][:60]][r["Counter_Name"]] += float(r["Counter_Value"])
+dur = collections.defaultdict(float)
+kt = find("sq", "kernel_trace.csv")
+if kt:
+    for r in csv.DictReader(open(kt)):
+        dur[r["Kernel_Name"][:60]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+with open(O + "/sq_summary.md", "w") as fo:
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:6]:
+        t = dur.get(k, 0.0)
+        clk = v.get("GRBM_GUI_ACTIVE", 0) / 8 / t / 1e9 if t else 0
+        simd_cycles = clk * 1e9 * t * 1024
+        fo.write(f"{k}\n  wall {t*1e3:.2f} ms, effective clock {clk:.3f} GHz, MFMA-busy / (1024 SIMDs x wall x clock) = "
+                 f"{v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / simd_cycles if simd_cycles else 0:.3f}\n")
+        for c, x in sorted(v.items()):
+            fo.write(f"    {c:28s} {x:.4g}\n")
+print(open(O + "/sq_summary.md").read()[:3000])
 PY
