@@ -251,6 +251,13 @@ size_t oai_icon_workspace_bytes(const oai_icon* h);
 int oai_icon_forward(oai_icon* h, const float* A_dev, const float* B_dev, float* phi_dev,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* oai_icon_forward replays its ~70 dependent launches as ONE hipGraph (captured on the first call per workspace, on an internal
+ * stream; inputs and result have fixed homes inside the workspace, copied in / out around the replay).  oai_icon_set_graph(h, 0)
+ * runs the same launches directly.  oai_icon_graph_info: *captured = 1 graph in use, 0 not captured yet, -1 capture failed on this
+ * runtime (direct launches are used: same kernels, same results); counts of replays / direct runs. */
+int oai_icon_set_graph(oai_icon* h, int enable);
+int oai_icon_graph_info(const oai_icon* h, int* captured, long long* replays, long long* direct_runs);
+
 /* One tallUNet2 forward on its own (unit-test seam): out[3][D][H][W] = net(a, b). */
 int oai_icon_unet_forward(oai_icon* h, int which, const float* a_dev, const float* b_dev, int D, int H, int W,
                           float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);

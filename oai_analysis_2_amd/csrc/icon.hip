@@ -22,9 +22,13 @@ constexpr int kUpIn[5] = {48, 96, 192, 512, 512};
 constexpr float kLeaky = 0.01f;
 constexpr float kBnEps = 1e-5f;
 constexpr long long kSplitKBelow = 16384;     // output voxels (per launch / per parity class) below which K is split over threads
+constexpr long long kMfmaUpFrom = 2048;       // output voxels per parity class from which the up-conv runs on MFMA (icon_up_mfma_kernel)
 constexpr long long kFewBlocks = 1024;        // split-K launches with fewer workgroups than this use 4 couts per block (4x the blocks)
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : v * kLeaky; }
+
+struct __attribute__((packed, aligned(4))) pair_f32s { float a, b; };       // 8-byte store at 4-byte alignment (dwordx2)
+__device__ __forceinline__ void pair_store(float* p, float a, float b) { *reinterpret_cast<pair_f32s*>(p) = pair_f32s{a, b}; }
 
 // Conv3d k3 p1, stride S, on leaky_relu(x) (PRE) + bias, optional residual
 //   RES: + avg_pool3d(x,2,ceil_mode=True) zero-padded IN FRONT to Cout channels (UNet2 down path)
@@ -182,6 +186,163 @@ icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
     }
 }
 
+// ---- MFMA up-conv for the big levels (full and half resolution: 0.75 of the nets' FLOPs) ----------------------------------------
+// ConvTranspose3d k4 s2 p1 as a GEMM per output row: an output voxel (oz, oy, ox = 2 tx + px) takes 2 x 2 x 2 taps; along x the
+// two parities share their inputs:   px = 0: (kx 1, ix = tx) + (kx 3, ix = tx - 1)      px = 1: (kx 0, ix = tx + 1) + (kx 2, ix = tx)
+// so one wave owns 16 MB consecutive tx of one (oz, oy) row, BOTH x parities, 16 couts, on v_mfma_f32_16x16x4_f32 (exact fp32
+// products): A operand = weights (rows = couts), B operand = three x-shifted 16-voxel segments of leaky(x) (columns = tx), k = 4
+// input channels per instruction.  Per (kz, ky) tap pair and 4 channels: 4 weight fragments + 3 MB voxel fragments feed 4 MB
+// MFMAs -- one dword load per MFMA, straight from L1/L2 (the VALU kernel it replaces issued one load per 16 FMAs but 8 x fewer
+// FLOPs per instruction).  The C/D layout gives a lane 4 couts x 1 tx: with the two parities paired, every store instruction
+// writes four full 128-byte lines (the VALU kernel wrote every other float of a line).  Epilogue as icon_up_kernel: + bias +
+// trilinear x2 residual of x[:Cout] (same expression, same order) -> BatchNorm -> crop.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int MB>
+__global__ void __launch_bounds__(256)
+icon_up_mfma_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
+                    const float* __restrict__ wk /*[Cin][64][Cout]*/, const float* __restrict__ bias,
+                    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                    float* __restrict__ out, int Cout, int Dc, int Hc, int Wc, int ntxb, long long nunits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long unit = (long long)blockIdx.x * 4 + wave;            // one wave = one (oz, oy, tx block); no barrier in this kernel
+    if (unit >= nunits) return;
+    const int txb = (int)(unit % ntxb);
+    const int rowi = (int)(unit / ntxb);
+    const int oy = rowi % Hc, oz = rowi / Hc;
+    const int co0 = blockIdx.y * 16;
+    const int pz = oz & 1, py = oy & 1, tz = oz >> 1, ty = oy >> 1;
+    const int col = lane & 15, kq = lane >> 4;
+    const long long plane = (long long)D * H * W;
+    f32x4m acc[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) acc[m][p] = f32x4m{0.0f, 0.0f, 0.0f, 0.0f};
+    const int tx0 = txb * MB * 16 + col;
+    for (int a = 0; a < 2; ++a) {
+        const int kz = pz ? 2 * a : 1 + 2 * a, iz = pz ? tz + 1 - a : tz - a;          // o = 2 i - 1 + k
+        if ((unsigned)iz >= (unsigned)D) continue;
+        for (int b = 0; b < 2; ++b) {
+            const int ky = py ? 2 * b : 1 + 2 * b, iy = py ? ty + 1 - b : ty - b;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            const float* xrow = x + ((long long)iz * H + iy) * W;
+            const float* wt = wk + (long long)((kz * 4 + ky) * 4) * Cout + co0 + col;
+            for (int ci0 = 0; ci0 < Cin; ci0 += 4) {
+                const int ci = ci0 + kq;
+                const float* wp = wt + (long long)ci * 64 * Cout;
+                const float w0 = wp[0], w1 = wp[Cout], w2 = wp[2 * Cout], w3 = wp[3 * Cout];
+                const float* xp = xrow + ci * plane;
+                float xm[MB], xc[MB], xq[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const int tx = tx0 + m * 16;
+                    xm[m] = (unsigned)(tx - 1) < (unsigned)W ? leaky(xp[tx - 1]) : 0.0f;
+                    xc[m] = tx < W ? leaky(xp[tx]) : 0.0f;
+                    xq[m] = tx + 1 < W ? leaky(xp[tx + 1]) : 0.0f;
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, xc[m], acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, xq[m], acc[m][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3, xm[m], acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2, xc[m], acc[m][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: lane = couts co0 + 4 kq + r (r = 0..3) of tx; the two parities are x-adjacent outputs
+    int z0, z1, y0, y1;
+    float a0, a1, b0, b1;
+    up_src(oz, D, z0, z1, a0, a1);
+    up_src(oy, H, y0, y1, b0, b1);
+    const long long oplane = (long long)Dc * Hc * Wc;
+    const int nxt = (Wc + 1) / 2;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int tx = tx0 + m * 16;
+        if (tx >= nxt) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 4 * kq + r;
+            const float* p = x + co * plane;          // pad_or_crop(x, Cout): the first Cout channels (Cin >= Cout)
+            auto at = [&](int zz, int yy, int xx) { return p[((long long)zz * H + yy) * W + xx]; };
+            float v[2];
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                int x0, x1;
+                float c0, c1;
+                up_src(2 * tx + px, W, x0, x1, c0, c1);
+                const float res = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
+                                  a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
+                const float t = (acc[m][px][r] + bias[co]) + res;
+                v[px] = t * bn_scale[co] + bn_shift[co];
+            }
+            float* o = out + co * oplane + ((long long)oz * Hc + oy) * Wc + 2 * tx;
+            if (2 * tx + 1 < Wc) { pair_store(o, v[0], v[1]); }
+            else o[0] = v[0];
+        }
+    }
+}
+
+// lastConv: Conv3d 18 -> 3, k3 p1, / 10, at full resolution.  N = 3 fills no MFMA tile; as a direct VALU convolution the first
+// version did one global load per 3 FMAs.  Here a thread owns 4 x-consecutive voxels x 3 couts: per (ci, dz, dy) it loads the 6
+// inputs x-1 .. x+4 once and does 36 FMAs (weights are wave-uniform scalar loads): 6 x fewer loads per FMA.
+__global__ void __launch_bounds__(256)
+icon_last_conv_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
+                      const float* __restrict__ wk /*[Cin][27][3]*/, const float* __restrict__ bias, float* __restrict__ out, float div) {
+    const int nxq = (W + 3) / 4;
+    const long long total = (long long)D * H * nxq;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int xq = (int)(id % nxq);
+    const int y = (int)((id / nxq) % H), z = (int)(id / ((long long)nxq * H));
+    const int xs = 4 * xq;
+    const long long plane = (long long)D * H * W;
+    float acc[4][3];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[v][j] = 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xp = x + ci * plane;
+        const float* wp = wk + (long long)ci * 27 * 3;
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int iz = z + dz - 1, iy = y + dy - 1;
+                const bool rowok = (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H;
+                const float* rp = xp + ((long long)(rowok ? iz : 0) * H + (rowok ? iy : 0)) * W;
+                float in[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int ix = xs - 1 + e;
+                    in[e] = rowok && (unsigned)ix < (unsigned)W ? rp[ix] : 0.0f;
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* w = wp + ((dz * 3 + dy) * 3 + dx) * 3;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc[v][j] = fmaf(in[v + dx], w[j], acc[v][j]);
+                }
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (xs + v < W) {
+                const float r = acc[v][j] + bias[j];
+                out[j * plane + ((long long)z * H + y) * W + xs + v] = div == 1.0f ? r : r / div;
+            }
+}
+
 struct NetWeights {
     float* down_w[5]; float* down_b[5];
     float* up_w[5]; float* up_b[5]; float* bn_s[5]; float* bn_t[5];
@@ -194,6 +355,13 @@ struct oai_icon {
     NetWeights net[3];
     int D, H, W;
     std::vector<void*> allocs;
+    // hipGraph replay of the ~70 dependent launches of one direction (oai_icon_forward): captured once per workspace on an
+    // internal stream (the caller's stream may be the legacy null stream, which cannot be captured), replayed on the caller's.
+    bool use_graph = true, graph_broken = false;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    void* g_ws = nullptr;
+    long long replays = 0, direct_runs = 0;
 };
 
 namespace {
@@ -285,11 +453,14 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
     for (int l = 4; l >= 0; --l) {
         const float* src = l == 4 ? bottom : cat[l + 1];
         const long long per_par = (long long)((dm.d[l][0] + 1) / 2) * ((dm.d[l][1] + 1) / 2) * ((dm.d[l][2] + 1) / 2);
-        if (per_par >= kSplitKBelow) {
-            dim3 grid(oai::cdiv(per_par, 256), kUpOut[l] / 16, 8);
-            icon_up_kernel<16, 1><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
-                                                         nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
-                                                         dm.d[l][0], dm.d[l][1], dm.d[l][2]);
+        if (per_par >= kMfmaUpFrom) {                   // the big levels: MFMA (fp32 products), one wave per 32 tx of an output row
+            constexpr int MB = 2;
+            const int ntxb = (int)oai::cdiv((dm.d[l][2] + 1) / 2, 16 * MB);
+            const long long nunits = (long long)dm.d[l][0] * dm.d[l][1] * ntxb;
+            dim3 grid(oai::cdiv(nunits, 4), kUpOut[l] / 16);
+            icon_up_mfma_kernel<MB><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                          nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                          dm.d[l][0], dm.d[l][1], dm.d[l][2], ntxb, nunits);
         } else if ((long long)oai::cdiv(per_par, 32) * (kUpOut[l] / 16) * 8 >= kFewBlocks) {
             dim3 grid(oai::cdiv(per_par, 32), kUpOut[l] / 16, 8);
             icon_up_kernel<16, 8><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
@@ -308,9 +479,8 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
         }
         OAI_CHECK_LAUNCH();
     }
-    dim3 grid(oai::cdiv(dm.vox[0], 256), 1);
-    icon_conv3_kernel<1, 3, false, false, 1><<<grid, 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W, nw.last_w, nw.last_b,
-                                                                 out, 3, D, H, W, 10.0f);
+    icon_last_conv_kernel<<<oai::cdiv((long long)D * H * ((W + 3) / 4), 256), 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W,
+                                                                                           nw.last_w, nw.last_b, out, 10.0f);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
@@ -324,6 +494,7 @@ bool dims_ok(int D, int H, int W) {
 
 struct Ws {
     float *a, *b, *d1, *d2, *d3, *aw, *c1, *c2, *Aw, *unet;
+    float *A, *B, *phi;          // fixed homes of the inputs and of the result: what the captured graph reads and writes
     size_t total_bytes;
 };
 
@@ -337,6 +508,7 @@ Ws plan_ws(int D, int H, int W, char* base) {
     s.a = take(vl); s.b = take(vl); s.d1 = take(3 * vl); s.d2 = take(3 * vl); s.aw = take(vl);
     s.d3 = take(3 * vh); s.c1 = nullptr; s.c2 = nullptr; s.Aw = take(vh);     // (c1, c2: never materialised since the chains are fused)
     s.unet = take(unet_ws_floats(D, H, W));
+    s.A = take(vh); s.B = take(vh); s.phi = take(3 * vh);
     s.total_bytes = o;
     return s;
 }
@@ -384,6 +556,8 @@ int oai_icon_create(const oai_icon_unet_params nets[3], int D, int H, int W, oai
 
 void oai_icon_destroy(oai_icon* h) {
     if (!h) return;
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -403,14 +577,11 @@ int oai_icon_unet_forward(oai_icon* h, int which, const float* a, const float* b
     return unet_forward(h->net[which], a, b, D, H, W, out, (float*)ws, (hipStream_t)stream);
 }
 
-int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, void* ws, size_t ws_bytes, void* stream) {
-    OAI_CHECK_ARG(h && A && B && phi && ws, "oai_icon_forward: null pointer");
+// the launches of one direction, on `st`, reading s.A / s.B and writing s.phi (all inside the workspace)
+static int icon_forward_body(oai_icon* h, const Ws& s, hipStream_t st) {
     const int D = h->D, H = h->H, W = h->W;
     const int d = (D + 1) / 2, hh = (H + 1) / 2, w = (W + 1) / 2;
-    Ws s = plan_ws(D, H, W, (char*)ws);
-    if (s.total_bytes > ws_bytes)
-        return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_forward: workspace %zu B < %zu B", ws_bytes, s.total_bytes);
-    hipStream_t st = (hipStream_t)stream;
+    const float *A = s.A, *B = s.B;
     int rc;
 #define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
     RUN(oai_avgpool2_3d(A, 1, D, H, W, s.a, st));                                  // DownsampleRegistration.forward
@@ -426,8 +597,63 @@ int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, vo
     RUN(oai_warp_chain(nullptr, D, H, W, 2, f21, low, A, D, H, W, s.Aw, st));
     RUN(unet_forward(h->net[2], s.Aw, B, D, H, W, s.d3, s.unet, st));              // FFVF(u3)
     // c3 = id_h + d3 (shortcut); c4 = c3 + sample(d2, c3); phi = c4 + sample(d1, c4)
-    RUN(oai_warp_chain(s.d3, D, H, W, 2, f21, low, nullptr, 0, 0, 0, phi, st));
+    RUN(oai_warp_chain(s.d3, D, H, W, 2, f21, low, nullptr, 0, 0, 0, s.phi, st));
 #undef RUN
+    return OAI_OK;
+}
+
+int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, void* ws, size_t ws_bytes, void* stream) {
+    OAI_CHECK_ARG(h && A && B && phi && ws, "oai_icon_forward: null pointer");
+    const long long vh = (long long)h->D * h->H * h->W;
+    Ws s = plan_ws(h->D, h->H, h->W, (char*)ws);
+    if (s.total_bytes > ws_bytes)
+        return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_forward: workspace %zu B < %zu B", ws_bytes, s.total_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    OAI_CHECK_HIP(hipMemcpyAsync(s.A, A, vh * 4, hipMemcpyDeviceToDevice, st));
+    OAI_CHECK_HIP(hipMemcpyAsync(s.B, B, vh * 4, hipMemcpyDeviceToDevice, st));
+    bool replayed = false;
+    if (h->use_graph && !h->graph_broken) {
+        if (!h->gexec || h->g_ws != ws) {                       // first call (or another workspace): capture, do not execute
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->graph_broken = true;
+            hipGraph_t g = nullptr;
+            if (!h->graph_broken && hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = icon_forward_body(h, s, h->cap_stream);
+                const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+                if (rc != OAI_OK || e != hipSuccess || !g || hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0) != hipSuccess) {
+                    h->gexec = nullptr;
+                    h->graph_broken = true;                     // not an error: the same launches run directly below (oai_icon_graph_info tells)
+                }
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+            } else h->graph_broken = true;
+            h->g_ws = ws;
+        }
+        if (h->gexec) {
+            OAI_CHECK_HIP(hipGraphLaunch(h->gexec, st));
+            ++h->replays;
+            replayed = true;
+        }
+    }
+    if (!replayed) {
+        if (int rc = icon_forward_body(h, s, st)) return rc;
+        ++h->direct_runs;
+    }
+    OAI_CHECK_HIP(hipMemcpyAsync(phi, s.phi, 3 * vh * 4, hipMemcpyDeviceToDevice, st));
+    return OAI_OK;
+}
+
+int oai_icon_set_graph(oai_icon* h, int enable) {
+    OAI_CHECK_ARG(h, "oai_icon_set_graph: null handle");
+    h->use_graph = enable != 0;
+    return OAI_OK;
+}
+
+int oai_icon_graph_info(const oai_icon* h, int* captured, long long* replays, long long* direct_runs) {
+    OAI_CHECK_ARG(h, "oai_icon_graph_info: null handle");
+    if (captured) *captured = h->gexec ? 1 : (h->graph_broken ? -1 : 0);
+    if (replays) *replays = h->replays;
+    if (direct_runs) *direct_runs = h->direct_runs;
     return OAI_OK;
 }
 

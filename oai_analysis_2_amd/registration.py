@@ -135,6 +135,17 @@ class IconEngine:
             self.lib.oai_icon_destroy(h)
             self._h = None
 
+    def set_graph(self, enable: bool) -> None:
+        """hipGraph replay of one direction's launches (default on); off = the same launches issued one by one."""
+        _lib.check(self.lib.oai_icon_set_graph(self._h, int(enable)), "oai_icon_set_graph")
+
+    def graph_info(self):
+        """(captured, replays, direct_runs): captured 1 = graph in use, 0 = not captured yet, -1 = capture failed (direct launches)."""
+        import ctypes as C
+        cap, rep, dr = C.c_int(), C.c_longlong(), C.c_longlong()
+        _lib.check(self.lib.oai_icon_graph_info(self._h, C.byref(cap), C.byref(rep), C.byref(dr)), "oai_icon_graph_info")
+        return cap.value, rep.value, dr.value
+
     def unet(self, which: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         """One tallUNet2: a, b [D,H,W] -> displacement [3,D,H,W] (unit-test seam)."""
         a = a.to(self.device, torch.float32).contiguous()

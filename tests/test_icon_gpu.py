@@ -18,7 +18,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("shape", [(20, 24, 24), (17, 33, 21), (40, 48, 48)])
+@pytest.mark.parametrize("shape", [(20, 24, 24), (17, 33, 21), (40, 48, 48), (33, 45, 37)])   # the last two reach the MFMA up-conv; odd axes = crop + edges
 def test_tall_unet2(shape):
     from oai_analysis_2_amd.registration import IconEngine
     sd = make_icon_state_dict(1)
@@ -55,3 +55,28 @@ def test_phi_full_resolution_80x192x192():
     got = eng.phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy()
     ident = oicon.identity_map((80, 192, 192))[0].numpy()
     assert _rel(got - ident, ref - ident) < TOL
+
+
+def test_graph_replay_equals_direct_launches():
+    """oai_icon_forward replays one hipGraph per direction; results are bit-identical to issuing the same launches one by one,
+    on the default (null) stream and on a side stream, and the replay really happens (not a silent fall-back)."""
+    from oai_analysis_2_amd.registration import IconEngine
+    sd = make_icon_state_dict(2)
+    net = (40, 48, 48)
+    A, B = torch.from_numpy(make_volume(3, net)).cuda(), torch.from_numpy(make_volume(4, net)).cuda()
+    direct = IconEngine(sd, net_shape=net)
+    direct.set_graph(False)
+    ref = direct.phi(A, B)
+    assert direct.graph_info() == (0, 0, 1)
+    eng = IconEngine(sd, net_shape=net)
+    got1 = eng.phi(A, B)                                  # captures, then replays
+    got2 = eng.phi(B, A)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got3 = eng.phi(A, B)
+    torch.cuda.current_stream().wait_stream(side)
+    captured, replays, direct_runs = eng.graph_info()
+    assert captured == 1 and replays == 3 and direct_runs == 0, (captured, replays, direct_runs)
+    assert torch.equal(got1, ref) and torch.equal(got3, ref)
+    assert torch.equal(got2, direct.phi(B, A))
