@@ -17,8 +17,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "liboai_hip.so")
 ARCH = "gfx950"
+# -packed-fp32-ops (device code only; the host pass prints "not a recognized feature", filtered below): no v_pk_fma_f32 /
+# v_pk_mul_f32 / v_pk_add_f32.  Measured on MI355X (profiles/r02_packed_fp32_hazard.md): a gather kernel whose fp32 arithmetic
+# hipcc had SLP-packed into v_pk_* produced wrong values in 16-lane groups whenever it ran on a side stream beside the MFMA
+# convolution kernels (5 of 12 volumes), and never with scalar fp32 VALU ops -- same source, same launches.  Packed fp32 is also
+# slower beside MFMAs (MI355X_MICROARCH.md, "price of one filler").  Results are unchanged: a packed op is two IEEE ops.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=on"]
+         "-ffp-contract=on", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc() -> str:
@@ -59,8 +64,9 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), lib
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "not a recognized feature for this target" not in ln)
+        if verbose and err.strip():
+            print(err, file=sys.stderr)
         return obj
 
     if jobs:

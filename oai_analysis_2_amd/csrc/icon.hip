@@ -343,6 +343,31 @@ icon_last_conv_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
             }
 }
 
+// Device-to-device copies inside the registration path are KERNELS, not hipMemcpyAsync: on a non-blocking side stream the runtime's
+// async D2D copy was observed not to hold back the kernels queued behind it on the same stream (a later launch overwrote the
+// source while the copy was still reading it: scripts/dbg_graph_race.py) -- a kernel is stream-ordered by construction, and
+// captures into the graph as an ordinary kernel node.
+__global__ void __launch_bounds__(256) copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * 256;
+    if (((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+int copy_f32(const float* src, float* dst, long long n, hipStream_t st) {
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    copy_f32_kernel<<<(unsigned)blocks, 256, 0, st>>>(src, dst, n);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
 struct NetWeights {
     float* down_w[5]; float* down_b[5];
     float* up_w[5]; float* up_b[5]; float* bn_s[5]; float* bn_t[5];
@@ -422,8 +447,8 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
     for (int l = 0; l < 5; ++l) { cat[l] = ws + o; o += align256((size_t)(kUpOut[l] + kDown[l]) * dm.vox[l] * 4) / 4; }
     float* bottom = ws + o;
     // x = cat([a, b], 1) lives in the skip slice of cat_0
-    OAI_CHECK_HIP(hipMemcpyAsync(cat[0] + (size_t)kUpOut[0] * dm.vox[0], a, dm.vox[0] * 4, hipMemcpyDeviceToDevice, st));
-    OAI_CHECK_HIP(hipMemcpyAsync(cat[0] + (size_t)(kUpOut[0] + 1) * dm.vox[0], b, dm.vox[0] * 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = copy_f32(a, cat[0] + (size_t)kUpOut[0] * dm.vox[0], dm.vox[0], st)) return rc;
+    if (int rc = copy_f32(b, cat[0] + (size_t)(kUpOut[0] + 1) * dm.vox[0], dm.vox[0], st)) return rc;
     for (int l = 0; l < 5; ++l) {
         const float* src = cat[l] + (size_t)kUpOut[l] * dm.vox[l];
         float* dst = l < 4 ? cat[l + 1] + (size_t)kUpOut[l + 1] * dm.vox[l + 1] : bottom;
@@ -507,6 +532,7 @@ Ws plan_ws(int D, int H, int W, char* base) {
     Ws s;
     s.a = take(vl); s.b = take(vl); s.d1 = take(3 * vl); s.d2 = take(3 * vl); s.aw = take(vl);
     s.d3 = take(3 * vh); s.c1 = nullptr; s.c2 = nullptr; s.Aw = take(vh);     // (c1, c2: never materialised since the chains are fused)
+
     s.unet = take(unet_ws_floats(D, H, W));
     s.A = take(vh); s.B = take(vh); s.phi = take(3 * vh);
     s.total_bytes = o;
@@ -609,8 +635,8 @@ int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, vo
     if (s.total_bytes > ws_bytes)
         return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_forward: workspace %zu B < %zu B", ws_bytes, s.total_bytes);
     hipStream_t st = (hipStream_t)stream;
-    OAI_CHECK_HIP(hipMemcpyAsync(s.A, A, vh * 4, hipMemcpyDeviceToDevice, st));
-    OAI_CHECK_HIP(hipMemcpyAsync(s.B, B, vh * 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = copy_f32(A, s.A, vh, st)) return rc;
+    if (int rc = copy_f32(B, s.B, vh, st)) return rc;
     bool replayed = false;
     if (h->use_graph && !h->graph_broken) {
         if (!h->gexec || h->g_ws != ws) {                       // first call (or another workspace): capture, do not execute
@@ -639,8 +665,7 @@ int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, vo
         if (int rc = icon_forward_body(h, s, st)) return rc;
         ++h->direct_runs;
     }
-    OAI_CHECK_HIP(hipMemcpyAsync(phi, s.phi, 3 * vh * 4, hipMemcpyDeviceToDevice, st));
-    return OAI_OK;
+    return copy_f32(s.phi, phi, 3 * vh, st);
 }
 
 int oai_icon_set_graph(oai_icon* h, int enable) {

@@ -520,6 +520,11 @@ static double layer_flops(const oai_unet* h, int k, const Box& b) {
     return 2.0 * vox * taps * h->L[k].cin * h->L[k].cout;
 }
 
+__global__ void flag_snapshot_kernel(int* __restrict__ flag, int* __restrict__ dst) {
+    dst[0] = flag[0];
+    flag[0] = 0;
+}
+
 }  // namespace oai
 
 using namespace oai;
@@ -691,8 +696,8 @@ int oai_unet_range_flag(oai_unet* h, int reset, int* out, void* stream) {
 int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream) {
     OAI_CHECK_ARG(h && dst_dev, "oai_unet_range_flag_snapshot: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    OAI_CHECK_HIP(hipMemcpyAsync(dst_dev, h->range_flag, sizeof(int), hipMemcpyDeviceToDevice, st));
-    OAI_CHECK_HIP(hipMemsetAsync(h->range_flag, 0, sizeof(int), st));
+    flag_snapshot_kernel<<<1, 1, 0, st>>>(h->range_flag, dst_dev);       // a kernel: stream-ordered with the conv launches around it
+    OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
 

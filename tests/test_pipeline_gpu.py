@@ -97,3 +97,36 @@ def test_cohort_of_8_full_size_volumes_streams_and_matches_single_runs():
             for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
                 assert torch.equal(getattr(one, name).cpu(), getattr(r, name)), (i, name)
     assert seen == list(range(8))
+
+
+def test_registration_under_the_segmentation_equals_registration_alone():
+    """The overlapped pipeline runs the ICON kernels on a side stream UNDERNEATH the MFMA convolution kernels.  Alternating two
+    full-size volumes, phi of every overlapped run must be bit-identical to the registration run alone (nothing else on the GPU).
+    Regression test of round 2's finding (profiles/r02_packed_fp32_hazard.md): with hipcc's SLP-packed fp32 arithmetic
+    (v_pk_fma_f32 / v_pk_mul_f32) the fused warp-chain kernel returned wrong values in 16-lane groups in ~40 % of such runs --
+    invisible when the same volume is repeated (the wrong lanes differ from run to run, the stale-data checks do not apply) and
+    invisible to every single-kernel parity test.  The library is built without packed fp32 ops (build.py)."""
+    from oai_analysis_2_amd.pipeline import VolumePipeline
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    shape = (160, 384, 384)
+    atlas = Image(make_volume(1000, shape), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
+    pipe = VolumePipeline(UNetEngine(make_unet_state_dict(0), precision="fp16x3"), IconEngine(make_icon_state_dict(0, last_scale=0.1)), atlas)
+    vols = [torch.from_numpy(make_volume(i, shape)).cuda() for i in range(2)]
+    meta = Image(make_volume(0, shape), [0.36, 0.36, 0.7], [2.0, -3.0, 1.0])
+    clean = []
+    for v in vols:
+        clean.append(pipe.register(v).clone())
+        torch.cuda.synchronize()
+    seg = [pipe.segment(v).clone() for v in vols]
+    assert pipe.overlap_registration
+    bad = 0
+    for trial in range(10):
+        k = trial % 2
+        r = pipe.run(vols[k], meta)
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(r.phi, clean[k])) + int(not torch.equal(torch.stack([r.fc, r.tc]), seg[k]))
+    res = [pipe.run(vols[t % 2], meta, check=False) for t in range(4)]          # and queued back to back, unsynchronised
+    torch.cuda.synchronize()
+    bad += sum(int(not torch.equal(r.phi, clean[t % 2])) for t, r in enumerate(res))
+    assert bad == 0, f"{bad} overlapped runs differ from the clean ones"
