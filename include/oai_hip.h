@@ -205,6 +205,19 @@ int oai_stitch_blocks(const float* blocks_dev, int n_classes, int D, int H, int 
                       const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
                       float* maps_dev, void* stream);
 
+/* Partition.__call__ (image_transforms.py:395-455) as a standalone gather: tiles [tile_begin, tile_end) of the reference's
+ * z-major order, tiles_dev[t - tile_begin][tz][ty][tx] = reflect-padded volume (pad lo = overlap; numpy.pad 'reflect').  For
+ * callers that use Partition directly; oai_segment_tiles never materialises tiles. */
+int oai_partition_tiles(const float* vol_dev, int D, int H, int W, const int tile_zyx[3], const int overlap_zyx[3],
+                        int tile_begin, int tile_end, float* tiles_dev, void* stream);
+
+/* Partition.assemble(is_vote=True) (image_transforms.py:466-484): every tile votes with all its voxels (overlaps included);
+ * out_dev[D][H][W] (uint8) = index of the label plane with the most votes (lowest index on a tie, np.argmax).  tile_labels_dev
+ * [n_tiles][tz][ty][tx] int32 must hold values in [0, n_labels) -- the reference indexes its vote array with the label VALUE,
+ * so its labels are 0..L-1 too. */
+int oai_assemble_vote(const int* tile_labels_dev, int n_labels, int D, int H, int W, const int tile_zyx[3], const int overlap_zyx[3],
+                      unsigned char* out_dev, void* stream);
+
 /* Roofline instrumentation (bench.py): when enabled, every launch of the dominant kernel (the 3x3x3
  * implicit-GEMM conv) is bracketed by hipEvents on the launch stream.  oai_unet_profile_read waits for the
  * recorded events and returns their summed duration and launch count, then clears them. */

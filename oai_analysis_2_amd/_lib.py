@@ -59,6 +59,8 @@ SIGNATURES = {
     "oai_mesh_point_distance_grid": (_I, [_P, C.c_longlong, _P, _P, C.c_longlong, C.POINTER(C.c_float), _F, C.POINTER(C.c_int), _P, _Z, _P, _P]),
     "oai_image_normalize_workspace_bytes": (_Z, []),
     "oai_image_normalize": (_I, [_P, _Z, _F, _F, _F, _F, _P, _P, _P, _Z, _P]),
+    "oai_partition_tiles": (_I, [_P, _I, _I, _I, _I3, _I3, _I, _I, _P, _P]),
+    "oai_assemble_vote": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _P, _P]),
     "oai_unet_create": (_I, [C.POINTER(LayerParams), _F, C.POINTER(_P)]),
     "oai_unet_destroy": (None, [_P]),
     "oai_unet_set_precision": (_I, [_P, _I]),

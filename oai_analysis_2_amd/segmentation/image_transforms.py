@@ -34,23 +34,12 @@ class Partition(object):
         vol = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32)).cuda()
         eff, grid, n = self.geometry(vol.shape)
         t, o = [int(v) for v in self.tile_size], [int(v) for v in self.overlap_size]
-
-        def refl(idx, size):           # numpy.pad(mode='reflect') index map
-            p = 2 * (size - 1)
-            m = torch.remainder(idx, p)
-            return torch.where(m < size, m, p - m)
-
-        dev = vol.device
-        tiles = torch.empty((n, 1, *t), dtype=torch.float32, device=dev)
-        k = 0
-        for i in range(grid[0]):
-            zi = refl(torch.arange(i * eff[0] - o[0], i * eff[0] - o[0] + t[0], device=dev), vol.shape[0])
-            for j in range(grid[1]):
-                yi = refl(torch.arange(j * eff[1] - o[1], j * eff[1] - o[1] + t[1], device=dev), vol.shape[1])
-                for kk in range(grid[2]):
-                    xi = refl(torch.arange(kk * eff[2] - o[2], kk * eff[2] - o[2] + t[2], device=dev), vol.shape[2])
-                    tiles[k, 0] = vol[zi][:, yi][:, :, xi]
-                    k += 1
+        from .. import _lib
+        lib = _lib.load()
+        tiles = torch.empty((n, 1, *t), dtype=torch.float32, device=vol.device)
+        with torch.cuda.device(vol.device):          # the gather is a HIP kernel (oai_partition_tiles), not torch indexing
+            _lib.check(lib.oai_partition_tiles(vol.data_ptr(), *[int(v) for v in vol.shape], _lib.int3(t), _lib.int3(o), 0, n,
+                                               tiles.data_ptr(), torch.cuda.current_stream().cuda_stream), "oai_partition_tiles")
         sample = dict(sample)
         sample["image"] = tiles
         return sample
@@ -60,10 +49,10 @@ class Partition(object):
         size, the outer frame of ``crop_size`` zeroed (``crop_size`` indexed like the reference: [2] is z, [0] lands on numpy
         axis 1, [1] on axis 2; a zero component zeroes everything, :509-513).  Runs on the device (oai_stitch_blocks);
         returns float64 like the reference unless ``data_type`` is given."""
-        if is_vote:
-            raise NotImplementedError("is_vote=True (label voting over overlaps) is not on the prediction path (segmenter.py:126-129)")
         from .. import _lib
         lib = _lib.load()
+        if is_vote:
+            return self._assemble_vote(lib, tiles, if_itk, crop_size, data_type)
         t = torch.as_tensor(np.asarray(tiles) if not isinstance(tiles, torch.Tensor) else tiles).to(torch.float32)
         if t.dim() == 5:
             t = t[:, 0]
@@ -80,9 +69,49 @@ class Partition(object):
             _lib.check(lib.oai_stitch_blocks(blocks.data_ptr(), 1, D, H, W, _lib.int3((tz, ty, tx)), _lib.int3((oz, oy, ox)), crop,
                                              maps.data_ptr(), torch.cuda.current_stream().cuda_stream), "oai_stitch_blocks")
         out = maps[0].cpu().numpy().astype(data_type if data_type else np.float64)
+        return self._finish(out, if_itk)
+
+    def _finish(self, out, if_itk):
         if if_itk:
             img = Image(out)
             if getattr(self, "image", None) is not None:
                 img.CopyInformation(self.image)
             return img
         return out
+
+    def _assemble_vote(self, lib, tiles, if_itk, crop_size, data_type):
+        """The vote branch (image_transforms.py:466-484) on the device: labels must be the integers 0..L-1 (the reference indexes its
+        vote array with the label value); uint8 result, float64 once ``crop_size`` is applied (np.zeros canvas, :509-513)."""
+        from .. import _lib
+        t = torch.as_tensor(np.asarray(tiles) if not isinstance(tiles, torch.Tensor) else tiles)
+        if t.dim() == 5:
+            t = t[:, 0]
+        if t.is_floating_point():
+            raise IndexError("only integers are valid label indices (assemble(is_vote=True) indexes the vote array with the label value)")
+        tz, ty, tx = (int(v) for v in self.tile_size)
+        oz, oy, ox = (int(v) for v in self.overlap_size)
+        D, H, W = (int(v) for v in self.image_size)
+        eff, grid, n = tile_grid((D, H, W), (tz, ty, tx), (oz, oy, ox))
+        if t.shape[0] != n or tuple(t.shape[1:]) != (tz, ty, tx):
+            raise ValueError(f"assemble needs {n} tiles of {tz}x{ty}x{tx}, got {tuple(t.shape)}")
+        classes = np.unique(t.cpu().numpy())                              # label_class = np.unique(tiles), :468 (host metadata)
+        nlab = int(classes.size)
+        if int(classes.min()) < 0 or int(classes.max()) >= nlab:
+            raise IndexError(f"label {int(classes.max())} is out of bounds for the vote array of {nlab} label planes")
+        lab = t.to(torch.int32).contiguous().cuda()
+        if nlab > 16:
+            raise NotImplementedError("more than 16 label classes")
+        out = torch.empty((D, H, W), dtype=torch.uint8, device=lab.device)
+        with torch.cuda.device(lab.device):
+            _lib.check(lib.oai_assemble_vote(lab.data_ptr(), nlab, D, H, W, _lib.int3((tz, ty, tx)), _lib.int3((oz, oy, ox)),
+                                             out.data_ptr(), torch.cuda.current_stream().cuda_stream), "oai_assemble_vote")
+        res = out.cpu().numpy()
+        if data_type:
+            res = res.astype(data_type)
+        if crop_size is not None and len(crop_size):
+            cz, cy, cx = int(crop_size[2]), int(crop_size[0]), int(crop_size[1])
+            canvas = np.zeros(res.shape)                                   # float64, like the reference
+            if cz and cy and cx:                                           # [c:-c] with c == 0 is empty
+                canvas[cz:-cz, cy:-cy, cx:-cx] = res[cz:-cz, cy:-cy, cx:-cx]
+            res = canvas
+        return self._finish(res, if_itk)

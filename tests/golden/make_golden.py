@@ -37,6 +37,24 @@ def install_itk_shim():
     sys.modules["itk"] = itk
 
 
+def make_vote_fixture(Partition):
+    """Partition.assemble(is_vote=True) (image_transforms.py:466-484): 2- and 3-label tiles, with and without crop_size."""
+    rng = np.random.default_rng(3)
+    out = {}
+    for idx, (shape, patch, ovl, nlab) in enumerate([((21, 40, 37), (16, 16, 8), (4, 4, 2), 2), ((9, 50, 33), (24, 20, 8), (2, 6, 1), 3)]):
+        v = rng.random(shape, dtype=np.float32)
+        p = Partition(patch, ovl, padding_mode="reflect", mode="pred")
+        tiles = p({"image": v.copy(), "name": ""})["image"]
+        lab = torch.from_numpy(rng.integers(0, nlab, size=tuple(tiles[:, 0].shape)))
+        out[f"v{idx}_vol"], out[f"v{idx}_patch"], out[f"v{idx}_overlap"] = v, np.asarray(patch), np.asarray(ovl)
+        out[f"v{idx}_labels"] = lab.numpy().astype(np.int8)
+        out[f"v{idx}_vote"] = np.asarray(p.assemble(lab, is_vote=True, if_itk=False, crop_size=None))
+        out[f"v{idx}_vote_crop"] = np.asarray(p.assemble(lab, is_vote=True, if_itk=False, crop_size=ovl))
+        assert out[f"v{idx}_vote"].dtype == np.uint8 and out[f"v{idx}_vote_crop"].dtype == np.float64
+    np.savez_compressed(os.path.join(HERE, "partition_vote.npz"), **out)
+    print("partition_vote", {k: v.shape for k, v in out.items() if k.endswith("vote")})
+
+
 def main():
     install_itk_shim()
     sys.path.insert(0, REF)
@@ -47,6 +65,8 @@ def main():
 
     torch.set_num_threads(8)
     torch.manual_seed(0)
+    if "--only-vote" in sys.argv:
+        return make_vote_fixture(Partition)
 
     # ---- 1. UNet forward, small tile, BN off / on -------------------------------------------
     out = {}
@@ -128,6 +148,9 @@ def main():
     res["tc_prob"] = res["tc_prob"].astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "segment_small.npz"), **res)
     print("segment_small", res["fc_prob"].shape, float(res["fc_prob"].max()), int(res["fc_mask"].sum()), int(res["tc_mask"].sum()))
+
+    # ---- 4b. the label-vote branch of Partition.assemble ---------------------------------------
+    make_vote_fixture(Partition)
 
     # ---- 5. reference registry quirk: unknown names return None (networks.py:858-862) ---------
     assert get_network("nope") is None and get_network("UNet") is UNet

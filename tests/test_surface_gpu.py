@@ -97,5 +97,32 @@ def test_partition_call_and_assemble_like_the_reference():
         assert got.dtype == np.float64 and np.array_equal(got, ref.astype(np.float64))
     img = part.assemble(tiles, if_itk=True, crop_size=ovl)
     assert isinstance(img, Image) and np.allclose(img.spacing, [0.5, 0.5, 1.0])
-    with pytest.raises(NotImplementedError):
-        part.assemble(tiles, is_vote=True)
+    with pytest.raises(IndexError):
+        part.assemble(tiles, is_vote=True)                                    # float tiles cannot index the vote array (numpy semantics)
+
+
+def test_partition_vote_assemble_matches_reference_golden(golden_dir):
+    """Partition.assemble(is_vote=True) (image_transforms.py:466-484) against the reference's own output (partition_vote.npz):
+    label voting over the overlaps, np.argmax tie rule, uint8 result, float64 once crop_size is applied; and the gather of
+    Partition.__call__ (a HIP kernel) against the reference's tiles of the same cases."""
+    from oai_analysis_2_amd.segmentation.image_transforms import Partition
+    z = np.load(os.path.join(golden_dir, "partition_vote.npz"))
+    for idx in (0, 1):
+        patch, ovl = tuple(int(v) for v in z[f"v{idx}_patch"]), tuple(int(v) for v in z[f"v{idx}_overlap"])
+        part = Partition(patch, ovl)
+        tiles = part({"image": z[f"v{idx}_vol"], "name": ""})["image"]
+        lab = torch.from_numpy(z[f"v{idx}_labels"].astype(np.int64))
+        assert tuple(tiles.shape[2:]) == tuple(lab.shape[1:]) and tiles.shape[0] == lab.shape[0]
+        got = part.assemble(lab, is_vote=True, if_itk=False, crop_size=None)
+        assert got.dtype == np.uint8 and np.array_equal(got, z[f"v{idx}_vote"])
+        got = part.assemble(lab, is_vote=True, if_itk=False, crop_size=ovl)
+        assert got.dtype == np.float64 and np.array_equal(got, z[f"v{idx}_vote_crop"])
+    with pytest.raises(IndexError):
+        part.assemble(lab.float(), is_vote=True)                       # numpy: only integers are valid indices
+    with pytest.raises(IndexError):
+        part.assemble(lab * 5, is_vote=True)                           # label value >= number of label planes
+    c = np.load(os.path.join(golden_dir, "partition_cases.npz"))      # __call__: the reference's tiles of the ragged cases
+    for idx in (0, 1, 2):
+        part = Partition(tuple(int(v) for v in c[f"c{idx}_patch"]), tuple(int(v) for v in c[f"c{idx}_overlap"]))
+        tiles = part({"image": c[f"c{idx}_vol"], "name": ""})["image"]
+        assert np.array_equal(tiles.cpu().numpy(), c[f"c{idx}_tiles"])
