@@ -50,6 +50,23 @@ struct oai_unet {
     size_t ev_used = 0;
 };
 
+#ifdef OAI_DIAG
+static unsigned long long* g_diag_stamps = nullptr;
+static unsigned long long* diag_stamps() {
+    if (!g_diag_stamps && oai::diag_env("OAI_STAMPS", 0)) {
+        if (hipMalloc((void**)&g_diag_stamps, 16 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_diag_stamps, 0, 16 * sizeof(unsigned long long));
+    }
+    return g_diag_stamps;
+}
+extern "C" int oai_diag_stamps(unsigned long long out[16], int reset) {      // diagnostic builds only (not in include/oai_hip.h)
+    if (!g_diag_stamps) return 1;
+    if (hipMemcpy(out, g_diag_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (reset) (void)hipMemset(g_diag_stamps, 0, 16 * sizeof(unsigned long long));
+    return 0;
+}
+#endif
+
 namespace oai {
 
 static int conv_kc(int variant) { return variant == 1 ? 16 : 8; }
@@ -334,6 +351,9 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     a.pool_out = pool_out;
     a.range_flag = h->range_flag;
     { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }      // -DOAI_DIAG builds only; constant 0 otherwise
+#ifdef OAI_DIAG
+    a.stamps = diag_stamps();
+#endif
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
     a.out = out; a.Cout = L.cout; a.scale = h->precision == OAI_PREC_FP16X3 ? L.scale_f16 : L.scale; a.shift = L.shift;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : h->precision == OAI_PREC_BF16X6 ? 1 : 2];

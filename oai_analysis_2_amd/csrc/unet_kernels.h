@@ -58,6 +58,7 @@ struct ConvArgs {
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
     int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
     int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
+    unsigned long long* stamps = nullptr;    // -DOAI_DIAG builds: device array of phase cycle sums (oai_diag_stamps); never set in production
     int nblocks = 0, xcd_group = 0;          // split-resident kernel: true workgroup count and the XCD dealing granularity (see xcd_block_id)
     // split-resident kernel only: dc0 (1x1x1 conv) + sigmoid / threshold + centre crop fused into dc1's epilogue.  When head_w is
     // set the layer's own output is NOT written; every block voxel inside head_boxes[tile] goes to the kept-centre blocks instead.

@@ -139,6 +139,15 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     const int lx = wx * RX + row % RX, ly = wy * RY + row / RX;
     const int m_lo = max(0, blo[0] - oz0), m_hi = min(MREP, bhi[0] - oz0);
 
+    // -DOAI_DIAG: per-wave cycle sums of the phases of the chunk loop (s_memtime at the phase boundaries), atomically added to
+    // a.stamps[phase] by lane 0 at the end: [0] taps end -> barrier 1 entered (loop overhead), [1] barrier 1, [2] DMA issue,
+    // [3] DMA wait, [4] barrier 2, [5] 27 taps, [6] epilogue, [7] prologue, [8] waves, [9] chunks.  OAI_STAMP is empty in production.
+#ifdef OAI_DIAG
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_chunks = 0;
+#define OAI_STAMP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_sum[i] += now_ - st_last; st_last = now_; if ((i) == 5) ++st_chunks; } } while (0)
+#else
+#define OAI_STAMP(i) do { } while (0)
+#endif
     f32x16 acc[MREP][NREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
@@ -226,6 +235,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
     float4 acur[2][MREP];           // (a register prefetch of the next tap's A fragments was measured: no gain, and it costs MREP 2 its third workgroup per CU)
+    OAI_STAMP(7);
     if constexpr (RING) {
         const int arel = (ly * HX + lx) * 64;                          // this lane's voxel inside a plane, tap (dy, dx) = (0, 0)
         issue_plane(0, 0); issue_plane(0, 1); issue_plane(0, 2); issue_plane(0, 3);
@@ -297,10 +307,15 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                     dst[m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
             };
             for (int ch = 0; ch < nchunks; ++ch) {
+                OAI_STAMP(0);
                 __syncthreads();                                             // every wave is done reading the previous chunk
+                OAI_STAMP(1);
                 if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
+                OAI_STAMP(2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
+                OAI_STAMP(3);
                 __syncthreads();                                             // ... and everybody else's
+                OAI_STAMP(4);
                 load_a(acur[0], 0, 0);
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
@@ -330,6 +345,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
                 }
+                OAI_STAMP(5);
             }
         };
         const int ml = m_lo == 0 ? m_hi : MREP;                         // workgroup-uniform
@@ -481,6 +497,15 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         }
     }
     if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);           // fp16 cannot hold it: report, never silently inf
+#ifdef OAI_DIAG
+    OAI_STAMP(6);
+    if (a.stamps && lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_sum[i]);
+        atomicAdd(a.stamps + 8, 1ull);
+        atomicAdd(a.stamps + 9, st_chunks);
+    }
+#endif
+#undef OAI_STAMP
 }
 
 // ---- k2s2 up-conv, split-resident in and out ------------------------------------------------------------------------------

@@ -1,0 +1,26 @@
+"""Diagnostic build only (python -m oai_analysis_2_amd.build --diag; OAI_LIB_PATH=build/diag/liboai_hip_diag.so OAI_STAMPS=1):
+per-wave cycle budget of conv3_igemm_sres's chunk loop, from s_memtime stamps at the phase boundaries, per layer."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oai_analysis_2_amd import _lib
+from oai_analysis_2_amd.synth import make_unet_state_dict, make_volume
+from oai_analysis_2_amd.segmentation.engine import UNetEngine
+lib = C.CDLL(_lib.LIB_PATH)
+eng = UNetEngine(make_unet_state_dict(0), precision="fp16x3")
+vol = torch.from_numpy(make_volume(0)).cuda()
+names = {0: "loop->bar1", 1: "barrier 1", 2: "DMA issue", 3: "DMA wait", 4: "barrier 2", 5: "27 taps", 6: "epilogue", 7: "prologue"}
+for tiles in (32, 160):
+    eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), (0, tiles), 0, tiles)
+    torch.cuda.synchronize()
+    out = (C.c_ulonglong * 16)()
+    lib.oai_diag_stamps(out, 1)
+    eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), (0, tiles), 0, tiles)
+    torch.cuda.synchronize()
+    lib.oai_diag_stamps(out, 1)
+    waves, chunks = out[8], out[9]
+    tot = sum(out[i] for i in names)
+    print(f"{tiles} tiles: {waves} waves, {chunks} wave-chunks, {tot / waves:.0f} cycles per wave")
+    for i, n in names.items():
+        per = out[i] / (chunks if i < 6 else waves)
+        print(f"   {n:34s} {100 * out[i] / tot:5.1f} %   {per:9.0f} cycles per {'chunk' if i < 6 else 'block'}")
