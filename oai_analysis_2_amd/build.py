@@ -88,8 +88,9 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), lib
 DIAG_LIB = os.path.join(os.path.dirname(HERE), "build", "diag", "liboai_hip_diag.so")
 
 
-def build_diag(force: bool = False, extra_flags=()) -> str:
-    return build_library(force, True, ["-DOAI_DIAG", *extra_flags], DIAG_LIB, os.path.join(os.path.dirname(DIAG_LIB), "_obj"))
+def build_diag(force: bool = False, extra_flags=(), tag: str = "") -> str:
+    lib = DIAG_LIB.replace(".so", f"{tag}.so")
+    return build_library(force, True, ["-DOAI_DIAG", *extra_flags], lib, os.path.join(os.path.dirname(DIAG_LIB), "_obj" + tag))
 
 
 if __name__ == "__main__":

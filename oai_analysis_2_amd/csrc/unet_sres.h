@@ -142,11 +142,25 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     // -DOAI_DIAG: per-wave cycle sums of the phases of the chunk loop (s_memtime at the phase boundaries), atomically added to
     // a.stamps[phase] by lane 0 at the end: [0] taps end -> barrier 1 entered (loop overhead), [1] barrier 1, [2] DMA issue,
     // [3] DMA wait, [4] barrier 2, [5] 27 taps, [6] epilogue, [7] prologue, [8] waves, [9] chunks.  OAI_STAMP is empty in production.
+    // -DOAI_STAMP_SET=1 times the epilogue instead: [0] last tap -> first epilogue barrier passed (wave skew), [1] split + LDS image,
+    // [2] barriers, [3] copy-out stores, [4] fused dc0 dot products, [5] fused pool stores, [6] head write + tail, [7] whole chunk loop.
 #ifdef OAI_DIAG
-    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_chunks = 0;
-#define OAI_STAMP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_sum[i] += now_ - st_last; st_last = now_; if ((i) == 5) ++st_chunks; } } while (0)
+#ifndef OAI_STAMP_SET
+#define OAI_STAMP_SET 0
+#endif
+    unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_chunks = 0;
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define OAI_STAMP_(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_sum[i] += (unsigned)(now_ - st_last); st_last = now_; } } while (0)
+#if OAI_STAMP_SET == 0
+#define OAI_STAMP(i) do { OAI_STAMP_(i); if ((i) == 5) ++st_chunks; } while (0)
+#define OAI_STAMPB(i) do { } while (0)
+#else
+#define OAI_STAMP(i) do { if ((i) == 5) ++st_chunks; } while (0)
+#define OAI_STAMPB(i) OAI_STAMP_(i)
+#endif
 #else
 #define OAI_STAMP(i) do { } while (0)
+#define OAI_STAMPB(i) do { } while (0)
 #endif
     f32x16 acc[MREP][NREP];
 #pragma unroll
@@ -185,7 +199,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         for (int it = 0; it < NIT; ++it) {
             const unsigned char* g = poff[it] != kNoPiece ? cb + poff[it] : zero_rec;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lds + (it * 256 + wave * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + (it * 256 + wave * 64) * 16), 16, 0, 0);     // cache-policy bits sc0 / sc1 / nt on the DMA: measured, no effect (profiles/r02_conv_phases.md)
         }
     };
 
@@ -364,6 +378,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     // voxels, i.e. 4-byte pieces of 64-byte records; stored directly that is 128 dword stores per wave with 64-bit address
     // arithmetic each (13% of the whole segmentation, profiles/r01_ablation.md).  Instead the block's output image is built in
     // the (now idle) halo buffer, 128 B per voxel and cout half, and copied out 16 B per lane: 32 full-width stores per wave.
+    OAI_STAMPB(7);
     constexpr int TV = TZ * kTY * kTX;                                // voxels of the block
     constexpr int EIT = TV * 8 / 256;                                 // 16-byte pieces per thread and cout half
     static_assert(TV * 128 <= BUF && (TV * 8) % 256 == 0, "output image must fit the halo buffer");
@@ -387,6 +402,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         unsigned char* lrow = lds + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
         __syncthreads();                                              // halo reads / the previous half's copy-out are done
+        OAI_STAMPB(n == 0 ? 0 : 2);
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
@@ -414,7 +430,9 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 *reinterpret_cast<unsigned*>(dst + 32) = w_lo;
             }
         }
+        OAI_STAMPB(1);
         __syncthreads();
+        OAI_STAMPB(2);
         if (head) {
             // dc0 on this half's 32 channels, read back from the image exactly as head_sres_kernel reads format S from
             // memory (same join, same channel order: bit-identical logits), accumulated across the two halves
@@ -449,6 +467,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         *reinterpret_cast<const float4*>(lds + sidx * 16);
             }
         }
+        OAI_STAMPB(head ? 4 : 3);
         if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
             if (a.pool_out && !OAI_DBG_BIT(a, 32)) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
                 unsigned char* pb = reinterpret_cast<unsigned char*>(a.pool_out);
@@ -472,6 +491,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             }
         }
     }
+    OAI_STAMPB(5);
     if (head) {
         int hlo[3], hhi[3];
         tile_box(a.head_boxes, tile, blo, bhi, hlo, hhi);
@@ -499,13 +519,16 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);           // fp16 cannot hold it: report, never silently inf
 #ifdef OAI_DIAG
     OAI_STAMP(6);
+    OAI_STAMPB(6);
     if (a.stamps && lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_sum[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, (unsigned long long)st_sum[i]);
         atomicAdd(a.stamps + 8, 1ull);
-        atomicAdd(a.stamps + 9, st_chunks);
+        atomicAdd(a.stamps + 9, (unsigned long long)st_chunks);
     }
 #endif
 #undef OAI_STAMP
+#undef OAI_STAMPB
+#undef OAI_STAMP_
 }
 
 // ---- k2s2 up-conv, split-resident in and out ------------------------------------------------------------------------------

@@ -9,7 +9,10 @@ from oai_analysis_2_amd.segmentation.engine import UNetEngine
 lib = C.CDLL(_lib.LIB_PATH)
 eng = UNetEngine(make_unet_state_dict(0), precision="fp16x3")
 vol = torch.from_numpy(make_volume(0)).cuda()
-names = {0: "loop->bar1", 1: "barrier 1", 2: "DMA issue", 3: "DMA wait", 4: "barrier 2", 5: "27 taps", 6: "epilogue", 7: "prologue"}
+SET = int(os.environ.get("STAMP_SET", "0"))      # must match the -DOAI_STAMP_SET the diagnostic library was built with
+names = ({0: "loop->bar1", 1: "barrier 1", 2: "DMA issue", 3: "DMA wait", 4: "barrier 2", 5: "27 taps", 6: "epilogue", 7: "prologue"} if SET == 0 else
+         {0: "last tap -> 1st epilogue barrier", 1: "split + LDS image", 2: "barriers", 3: "copy-out stores", 4: "fused dc0 dots", 5: "fused pool stores",
+          6: "head write + tail", 7: "prologue + whole chunk loop"})
 for tiles in (32, 160):
     eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), (0, tiles), 0, tiles)
     torch.cuda.synchronize()
@@ -22,5 +25,6 @@ for tiles in (32, 160):
     tot = sum(out[i] for i in names)
     print(f"{tiles} tiles: {waves} waves, {chunks} wave-chunks, {tot / waves:.0f} cycles per wave")
     for i, n in names.items():
-        per = out[i] / (chunks if i < 6 else waves)
-        print(f"   {n:34s} {100 * out[i] / tot:5.1f} %   {per:9.0f} cycles per {'chunk' if i < 6 else 'block'}")
+        per_chunk = SET == 0 and i < 6
+        per = out[i] / (chunks if per_chunk else waves)
+        print(f"   {n:34s} {100 * out[i] / tot:5.1f} %   {per:9.0f} cycles per {'chunk' if per_chunk else 'block'}")
