@@ -463,8 +463,13 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 const int oz = oz0 + vox / (kTX * kTY), oy = oy0 + (vox / kTX) % kTY, ox = ox0 + vox % kTX;
                 const int chunk = cb * 4 + n * 2 + (q >> 2);
                 if (chunk < nco && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1] && ox >= blo[2] && ox < bhi[2])
-                    *reinterpret_cast<float4*>(outb + srec(tile, nco, plane, chunk, ((size_t)oz * a.H + oy) * a.W + ox) + (q & 3) * 16) =
-                        *reinterpret_cast<const float4*>(lds + sidx * 16);
+                {
+                    float4* dstp = reinterpret_cast<float4*>(outb + srec(tile, nco, plane, chunk, ((size_t)oz * a.H + oy) * a.W + ox) + (q & 3) * 16);
+                    const float4 val = *reinterpret_cast<const float4*>(lds + sidx * 16);
+                    // one global_store_dwordx4 ... nt: the tensor (GBs per layer) is next read by another launch, from HBM either way (-0.9 %)
+                    __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                    __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                }
             }
         }
         OAI_STAMPB(head ? 4 : 3);
