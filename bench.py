@@ -175,6 +175,13 @@ def dry_run(args, world, rank):
             b, e = parallel.slab_range_for_rank(nz, rank, world)
             slabs = parallel.gather_slabs(torch.arange(b, e, dtype=torch.float32)[None, :, None, None].expand(2, e - b, 3, 3).contiguous(), nz)
             assert slabs.shape == (2, nz, 3, 3) and torch.equal(slabs[0, :, 0, 0], torch.arange(nz, dtype=torch.float32))
+        elif args.mode == "cohort":
+            q = parallel.VolumeQueue(4 * world)
+            mine = list(q)
+            total = torch.tensor([len(mine)], dtype=torch.int64)
+            if world > 1:
+                dist.all_reduce(total)
+            assert int(total) == 4 * world and len(set(mine)) == len(mine)
         else:
             mine = parallel.volumes_for_rank(world * 2, rank, world)
             assert mine == [rank, rank + world]
@@ -227,9 +234,11 @@ def main():
                     help="arithmetic of the 3x3x3 conv layers.  fp16x3 (default): every fp32 operand split into two fp16 terms, "
                          "3 MFMA passes, fp32 accumulate -- fp32-grade results (same parity margins as f32 in tests/, incl. the full-size "
                          "reference golden); f32: exact fp32 MFMA; bf16x6 / bf16x3: split-bf16 with 6 / 3 passes")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "tileshard"],
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "tileshard", "cohort"],
                     help="N>1: replicas = one volume per rank per step (weak scaling, no collective); tileshard = every step "
-                         "is ONE volume whose 160 tiles are split over the ranks + one RCCL all_gather (strong scaling)")
+                         "is ONE volume whose 160 tiles are split over the ranks + one RCCL all_gather (strong scaling); cohort = "
+                         "BASELINE config 5's form: --steps x N volumes (64 at --steps 8 --gpus 8) in ONE shared queue, every rank claims "
+                         "the next volume when it is free (parallel.VolumeQueue) -- same work as replicas, dynamically assigned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in exact fp32 MFMA (full --steps) reported beside the primary")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
@@ -296,7 +305,40 @@ def main():
             return pipe.run_sharded(vols[i % n_distinct] if rank == 0 else None, meta, check=False)   # the volume lives on rank 0: broadcast inside
         return pipe.run(vols[i % n_distinct], meta, check=False)
 
-    dt, conv_ms, conv_launches, overflow = measure(step, unet, args.steps, args.warmup, use_dist, dist)
+    if args.mode == "cohort":
+        from oai_analysis_2_amd.parallel import VolumeQueue
+        warm_q, timed_q = VolumeQueue(args.warmup * world), VolumeQueue(args.steps * world)      # constructed in the same order on every rank
+        claimed = []
+
+        def run_queue(q):
+            flags = []
+            for i in q:
+                claimed.append(i)
+                flags.append(pipe.run(vols[i % n_distinct], meta, check=False).overflow)
+            return flags
+
+        run_queue(warm_q)
+        torch.cuda.synchronize()
+        unet.profile_read()
+        unet.profile(True)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        claimed.clear()
+        t0 = time.perf_counter()
+        flags = run_queue(timed_q)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        conv_ms, conv_launches = unet.profile_read()
+        unet.profile(False)
+        overflow = any(int(f.item()) for f in flags if f is not None)
+        my_volumes = len(claimed)
+    else:
+        dt, conv_ms, conv_launches, overflow = measure(step, unet, args.steps, args.warmup, use_dist, dist)
+        my_volumes = args.steps
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -304,7 +346,7 @@ def main():
 
     if rank == 0:
         _, _, n_tiles = tile_grid(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX)
-        if args.mode == "replicas":
+        if args.mode in ("replicas", "cohort"):
             my_frac = 1.0
         else:                                        # rank 0's share of the volume's work under the cost-balanced tile split
             costs = unet.tile_costs(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX)
@@ -345,16 +387,17 @@ def main():
 
         out = {
             "metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32",
-            "value": (world if args.mode == "replicas" else 1) * args.steps / dt, "unit": "volumes/s",
+            "value": (1 if args.mode == "tileshard" else world) * args.steps / dt, "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.mode == "tileshard" else "weak", "vs_baseline": None,
             "dtype": DTYPE_OF[args.precision], "data": "synthetic",
             "config": {"workload": "fused segment->register->resample per volume, 1 volume per GPU per step, 384x384x160 fp32, "
                                    "160 tiles of 128x128x32 (overlap 16/16/8), ICON 80x192x192 one direction, FC+TC resample",
                        "tiles_per_pass": getattr(unet, "last_batch", args.batch), "parallelism": f"{args.mode} x{world}",
                        "collective_backend": ("nccl (RCCL)" if use_dist else None), "world_size": world,
-                       "options": args.option or None},
-            "roofline": roofline(args.precision, conv_ms, conv_launches, args.steps, my_frac),
+                       "options": args.option or None,
+                       "cohort": ({"volumes": args.steps * world, "claimed_by_rank0": my_volumes} if args.mode == "cohort" else None)},
+            "roofline": roofline(args.precision, conv_ms, conv_launches, my_volumes, my_frac),
             "fp16_range_overflow": overflow,
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
             "segment_frame_aware_tflop_per_volume": unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, False) / 1e12,

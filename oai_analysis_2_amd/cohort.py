@@ -81,24 +81,33 @@ class CohortRunner:
             out = self._download(res, done)
         return out
 
-    def run(self, images: Sequence, rank: int = 0, world: int = 1) -> Iterator[Tuple[int, VolumeResult]]:
-        """Yield (index, result) for the volumes this rank owns (index % world == rank), in order."""
-        mine = [i for i in range(len(images)) if i % world == rank]
-        if not mine:
+    def run(self, images: Sequence, rank: int = 0, world: int = 1, queue=None) -> Iterator[Tuple[int, VolumeResult]]:
+        """Yield (index, result) for the volumes this worker processes, in its processing order.  ``queue`` (a
+        ``parallel.VolumeQueue`` shared by all ranks) assigns volumes dynamically -- the worker claims one volume ahead, so that its
+        upload overlaps the current compute; without a queue the static split index % world == rank is used."""
+        if queue is not None:
+            order = iter(queue)
+        else:
+            order = iter([i for i in range(len(images)) if i % world == rank])
+        cur = next(order, None)
+        if cur is None:
             return
-        imgs = {i: as_image(images[i]) for i in mine}
-        nxt = self._upload(imgs[mine[0]], 0)
-        pending = None                                                    # (index, device results, completion event) of the previous volume
-        for k, i in enumerate(mine):
+        nxt = self._upload(as_image(images[cur]), 0)
+        pending = None                                                    # (index, device results, completion event, ...) of the previous volume
+        k = 0
+        while cur is not None:
+            img = as_image(images[cur])
             dev, ev = nxt
             torch.cuda.current_stream().wait_event(ev)
             dev.record_stream(torch.cuda.current_stream())                # allocated on the copy stream, read by the compute stream
-            res = self.pipe.run(dev, imgs[i], check=False)                # queued, not waited for; the range flag is read at download time
+            res = self.pipe.run(dev, img, check=False)                    # queued, not waited for; the range flag is read at download time
             done = torch.cuda.Event()
             done.record()
-            if k + 1 < len(mine):
-                nxt = self._upload(imgs[mine[k + 1]], (k + 1) & 1)        # host staging + H2D behind this volume's compute
+            following = next(order, None)                                 # claimed now: its host staging + H2D run behind this volume's compute
+            if following is not None:
+                nxt = self._upload(as_image(images[following]), (k + 1) & 1)
             if pending is not None:
                 yield pending[0], self._finish(pending)
-            pending = (i, res, done, dev, imgs[i])
+            pending = (cur, res, done, dev, img)
+            cur, k = following, k + 1
         yield pending[0], self._finish(pending)

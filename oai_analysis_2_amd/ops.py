@@ -19,6 +19,24 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_tensor_device(fn):
+    """Run ``fn`` with the device of its first tensor argument current: the C ABI launches on the current HIP device and takes the
+    current stream, so a tensor on another GPU of the process must switch both."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if torch.is_tensor(a) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+            if isinstance(a, (list, tuple)) and a and torch.is_tensor(a[0]) and a[0].is_cuda:
+                with torch.cuda.device(a[0].device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
+
+
 def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.OaiError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
@@ -27,6 +45,7 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+@_on_tensor_device
 def grid_sample3d(src: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optional[Sequence[int]] = None) -> torch.Tensor:
     """src [C,d,h,w], coords [3,D,H,W] in [0,1] (None = identity of out_shape) -> [C,D,H,W]."""
     lib = _lib.load()
@@ -43,6 +62,7 @@ def grid_sample3d(src: torch.Tensor, coords: Optional[torch.Tensor], out_shape: 
     return out
 
 
+@_on_tensor_device
 def compose(disp: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optional[Sequence[int]] = None,
             shortcut: bool = True) -> torch.Tensor:
     """coords + sample(disp, coords); coords None = identity map of out_shape (or of disp's grid)."""
@@ -60,6 +80,7 @@ def compose(disp: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optio
     return out
 
 
+@_on_tensor_device
 def warp_chain(out_shape: Sequence[int], fields: Sequence[torch.Tensor] = (), start: Optional[torch.Tensor] = None,
                image: Optional[torch.Tensor] = None) -> torch.Tensor:
     """c = identity(out_shape) [+ start]; c = c + sample(f, c) for f in fields (<= 2); returns sample(image, c) [D,H,W] when an
@@ -88,6 +109,7 @@ def warp_chain(out_shape: Sequence[int], fields: Sequence[torch.Tensor] = (), st
     return out
 
 
+@_on_tensor_device
 def avgpool2(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _chk(x, "x")
@@ -97,6 +119,7 @@ def avgpool2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def resize_trilinear(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
     lib = _lib.load()
     x = _chk(x, "x")
@@ -107,6 +130,7 @@ def resize_trilinear(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def phi_to_itk_displacement(phi: torch.Tensor) -> torch.Tensor:
     """phi [3,D,H,W] -> float64 [D,H,W,3] (xyz components, network voxel units)."""
     lib = _lib.load()
@@ -124,6 +148,7 @@ def make_affine(A: np.ndarray, b: np.ndarray) -> _lib.Affine:
     return a
 
 
+@_on_tensor_device
 def resample_through_disp(prob: torch.Tensor, disp: torch.Tensor, b_index_to_net, net_to_a_index,
                           out_shape_zyx: Sequence[int]) -> torch.Tensor:
     lib = _lib.load()
@@ -140,6 +165,7 @@ def resample_through_disp(prob: torch.Tensor, disp: torch.Tensor, b_index_to_net
     return out
 
 
+@_on_tensor_device
 def resample_maps_through_phi(maps: torch.Tensor, phi: torch.Tensor, b_index_to_net, net_to_a_index,
                               out_shape_zyx: Sequence[int]) -> torch.Tensor:
     """maps [n,zA,yA,xA] (n <= 4) pulled through the dense map phi [3,D,H,W] onto a grid of ``out_shape_zyx``: one launch,
@@ -161,6 +187,7 @@ def resample_maps_through_phi(maps: torch.Tensor, phi: torch.Tensor, b_index_to_
     return out
 
 
+@_on_tensor_device
 def image_normalize(vol: torch.Tensor, window_min_perc: float = 0.1, window_max_perc: float = 99.9,
                     output_min: float = 0.0, output_max: float = 1.0, return_window: bool = False):
     """``image_normalize`` of oai_analysis/dask_processing.py:10-26 on the device (fp32 image)."""

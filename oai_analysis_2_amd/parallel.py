@@ -139,3 +139,43 @@ def any_rank(flag: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     return flag
+
+
+# ---- cohort scheduling: a volume queue instead of a static assignment -------------------------------------
+
+class VolumeQueue:
+    """Dynamic assignment of the volumes of a cohort to persistent per-GPU workers: every rank claims the next unprocessed index
+    with one atomic add on the process group's key-value store (TCPStore on rank 0).  A rank that is slower -- its volumes needed
+    the fp32 repeat, its GPU is clocked lower (devices differ by up to 12 %, MI355X_MICROARCH.md) -- simply claims fewer volumes,
+    where the static ``v % world`` split of ``volumes_for_rank`` (and the reference's Dask graph, which rebuilds the models per
+    task, dask_processing.py:77,170) would wait for it.  Without an initialised process group it is a local counter."""
+
+    _serial = 0
+
+    def __init__(self, n_volumes: int, name: Optional[str] = None):
+        self.n = int(n_volumes)
+        self._local = 0
+        self._store = None
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d
+            self._store = distributed_c10d._get_default_store()
+            if name is None:                       # every rank constructs its queues in the same order: same key on all ranks
+                name = f"oai_volume_queue_{VolumeQueue._serial}"
+                VolumeQueue._serial += 1
+            self._key = name
+
+    def claim(self) -> Optional[int]:
+        """Index of the next volume, or None when the cohort is exhausted.  Each index is handed out exactly once across ranks."""
+        if self._store is None:
+            i = self._local
+            self._local += 1
+        else:
+            i = int(self._store.add(self._key, 1)) - 1
+        return i if i < self.n else None
+
+    def __iter__(self):
+        while True:
+            i = self.claim()
+            if i is None:
+                return
+            yield i

@@ -138,7 +138,7 @@ def test_broadcast_flag_agreement_and_slab_gather(tmp_path, world):
     assert all((tmp_path / f"ok_{r}").read_text() == "1" for r in range(world))
 
 
-@pytest.mark.parametrize("mode", ["tileshard", "replicas"])
+@pytest.mark.parametrize("mode", ["tileshard", "replicas", "cohort"])
 def test_bench_spawns_its_own_ranks(mode):
     """`python bench.py --gpus 2` with no launcher around it must start its ranks itself: exercised with --dry-run
     (CPU tensors over gloo, the product's parallel.py, no kernels)."""
@@ -157,3 +157,35 @@ def test_bench_spawns_its_own_ranks(mode):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
     if not torch.cuda.is_available():
         assert r.returncode == 2 and "requested" in r.stderr
+
+
+def _worker_queue(rank, world, port, n, out_dir):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q = parallel.VolumeQueue(n)
+    got = []
+    for i in q:
+        got.append(i)
+        time.sleep(0.02 * (1 + 3 * (rank == 0)))                 # rank 0 is four times slower: it must end up with fewer volumes
+    assert q.claim() is None
+    q2 = parallel.VolumeQueue(5)                                  # a second queue gets its own key on every rank
+    got2 = list(q2)
+    with open(os.path.join(out_dir, f"q_{rank}"), "w") as f:
+        f.write(",".join(map(str, got)) + ";" + ",".join(map(str, got2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_volume_queue_hands_out_every_volume_once_and_balances(tmp_path):
+    world, n = 3, 40
+    mp.spawn(_worker_queue, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    firsts, seconds = [], []
+    for r in range(world):
+        a, b = (tmp_path / f"q_{r}").read_text().split(";")
+        firsts.append([int(v) for v in a.split(",") if v])
+        seconds.append([int(v) for v in b.split(",") if v])
+    assert sorted(sum(firsts, [])) == list(range(n)) and sorted(sum(seconds, [])) == list(range(5))
+    assert len(firsts[0]) < min(len(firsts[1]), len(firsts[2]))           # the slow rank claimed fewer
+    q = parallel.VolumeQueue(3)                                           # no process group: a local counter
+    assert list(q) == [0, 1, 2] and q.claim() is None
