@@ -54,15 +54,15 @@ struct oai_unet {
 static unsigned long long* g_diag_stamps = nullptr;
 static unsigned long long* diag_stamps() {
     if (!g_diag_stamps && oai::diag_env("OAI_STAMPS", 0)) {
-        if (hipMalloc((void**)&g_diag_stamps, 16 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_diag_stamps, 0, 16 * sizeof(unsigned long long));
+        if (hipMalloc((void**)&g_diag_stamps, 32 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_diag_stamps, 0, 32 * sizeof(unsigned long long));
     }
     return g_diag_stamps;
 }
-extern "C" int oai_diag_stamps(unsigned long long out[16], int reset) {      // diagnostic builds only (not in include/oai_hip.h)
+extern "C" int oai_diag_stamps(unsigned long long out[32], int reset) {      // diagnostic builds only (not in include/oai_hip.h)
     if (!g_diag_stamps) return 1;
-    if (hipMemcpy(out, g_diag_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 2;
-    if (reset) (void)hipMemset(g_diag_stamps, 0, 16 * sizeof(unsigned long long));
+    if (hipMemcpy(out, g_diag_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (reset) (void)hipMemset(g_diag_stamps, 0, 32 * sizeof(unsigned long long));
     return 0;
 }
 #endif
@@ -398,6 +398,9 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.range_flag = h->range_flag;
     a.zero = h->zero_rec;
     { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }
+#ifdef OAI_DIAG
+    a.stamps = diag_stamps();
+#endif
     const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
     a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
     a.wpanel = split ? L.panel_bf[2] : L.panel;

@@ -508,6 +508,7 @@ struct UpArgs {
     const int* boxes;                   // optional [tile][6]: the part of the INPUT box this tile needs
     int* range_flag;                    // split-fp16: set when an input is outside fp16's range
     const unsigned char* zero = nullptr; // split-resident kernel: 64 zero bytes, the LDS-DMA source of rows / columns that do not exist
+    unsigned long long* stamps = nullptr;   // -DOAI_DIAG builds: phase cycle sums of the up-conv kernel at stamps[16..31]
     int dbg = 0;                        // diagnostic timing switches (OAI_DBG bits 64/128/256/512; results wrong when set)
 };
 

@@ -548,6 +548,14 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 // MFMAs with counted vmcnt waits and ONE barrier per step: with direct register loads each of the 8-32 k steps waited a
 // full L2 round trip with only two waves per SIMD to hide it (1.9 TB/s of writes on dc3).
 __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
+#ifdef OAI_DIAG
+    // phase stamps (scripts/stamp_phases.py): [16] prologue, [17] k loop, [18] epilogue barriers, [19] split + LDS image, [20] copy-out stores, [24] waves
+    unsigned ust[5] = {0, 0, 0, 0, 0};
+    unsigned long long ulast = __builtin_amdgcn_s_memtime();
+#define OAI_USTAMP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ust[i] += (unsigned)(now_ - ulast); ulast = now_; } } while (0)
+#else
+#define OAI_USTAMP(i) do { } while (0)
+#endif
     constexpr int kStage = 24 * 1024, kRing = 3 * kStage;                            // [A 8 KB | B 4 x 4 KB] per stage
     __shared__ __attribute__((aligned(16))) unsigned char ulds[kRing + 512];          // ring (the 64-KB epilogue image reuses it) + voxel table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -628,6 +636,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         for (int k = 0; k < 2; ++k) aoff[k][m] = vl * 64 + (((k * 2 + half) ^ ((vl >> 2) & 3)) << 4);
     }
     const int boff = 8192 + wn * 8192 + lane * 16;                         // this wave's two column groups, fragment (k, nr) at + (k*2+nr)*1024
+    OAI_USTAMP(0);
     issue(0, 0);
     if (nks > 1) issue(1, 1);
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
@@ -655,6 +664,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                     for (int n = 0; n < 4; ++n) acc[m][n] = mfma_16bit<true>(at[PA[p]][m], bf[PB[p]][n], acc[m][n]);
         }
     }
+    OAI_USTAMP(1);
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + srec(tile, nco, 8 * plane, 0, 0);      // chunk c of output voxel v at + (c * 8 plane + v) * 64
     if (a.Cout % 16 == 0) {
         // ---- epilogue through LDS, one 64-voxel half (m) at a time: records [voxel 64][16 column chunks][64 B], copied out
@@ -669,6 +679,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
+            OAI_USTAMP(2);
             if (active && !OAI_DBG_BIT(a, 512)) {
                 unsigned vmask = 0;                                          // which of this lane's 16 voxel rows are real outputs
 #pragma unroll
@@ -701,7 +712,9 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                     }
                 }
             }
+            OAI_USTAMP(3);
             __syncthreads();
+            OAI_USTAMP(2);
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int vl = it * 4 + (tid >> 6);                          // image row: block voxel (vl >> 5) * 64 + m * 32 + (vl & 31)
@@ -709,8 +722,16 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                 if (qok && e != ~0u && !OAI_DBG_BIT(a, 64))
                     *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
             }
+            OAI_USTAMP(4);
         }
         if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);
+#ifdef OAI_DIAG
+        OAI_USTAMP(4);
+        if (a.stamps && lane == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(a.stamps + 16 + i, (unsigned long long)ust[i]);
+            atomicAdd(a.stamps + 24, 1ull);
+        }
+#endif
         return;
     }
     // ---- narrow test networks (Cout not a multiple of 16): dword stores straight from the accumulators

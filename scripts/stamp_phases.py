@@ -16,7 +16,7 @@ names = ({0: "loop->bar1", 1: "barrier 1", 2: "DMA issue", 3: "DMA wait", 4: "ba
 for tiles in (32, 160):
     eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), (0, tiles), 0, tiles)
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     lib.oai_diag_stamps(out, 1)
     eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), (0, tiles), 0, tiles)
     torch.cuda.synchronize()
@@ -28,3 +28,9 @@ for tiles in (32, 160):
         per_chunk = SET == 0 and i < 6
         per = out[i] / (chunks if per_chunk else waves)
         print(f"   {n:34s} {100 * out[i] / tot:5.1f} %   {per:9.0f} cycles per {'chunk' if per_chunk else 'block'}")
+    if out[24]:
+        un = ["prologue", "k loop (DMA ring + MFMAs)", "epilogue barriers", "split + LDS image", "copy-out stores"]
+        ut = sum(out[16 + i] for i in range(5))
+        print(f"   upconv2_igemm_sres: {out[24]} waves, {ut / out[24]:.0f} cycles per wave")
+        for i, n in enumerate(un):
+            print(f"      {n:30s} {100 * out[16 + i] / ut:5.1f} %   {out[16 + i] / out[24]:9.0f} cycles per block")
