@@ -59,7 +59,7 @@ icon_conv3_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
         for (int ci = ks; ci < Cin; ci += KS) {
             const float* xp = x + ci * plane;
             const float* wp = wk + ((long long)ci * 27) * Cout + cg * COUT_T;
-#pragma unroll 3
+#pragma unroll 9
             for (int t = 0; t < 27; ++t) {
                 const int iz = iz0 + t / 9, iy = iy0 + (t / 3) % 3, ix = ix0 + t % 3;
                 float in = 0.0f;
@@ -144,7 +144,7 @@ icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
         for (int ci = ks; ci < Cin; ci += KS) {
             const float* xp = x + ci * plane;
             const float* wp = wk + ((long long)ci * 64) * Cout + cg * COUT_T;
-#pragma unroll 2
+#pragma unroll 8
             for (int t = 0; t < 8; ++t) {
                 const int kz = qz + 2 * (t >> 2), ky = qy + 2 * ((t >> 1) & 1), kx = qx + 2 * (t & 1);
                 const int iz = (oz + 1 - kz) >> 1, iy = (oy + 1 - ky) >> 1, ix = (ox + 1 - kx) >> 1;
@@ -198,15 +198,19 @@ icon_up_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
 // trilinear x2 residual of x[:Cout] (same expression, same order) -> BatchNorm -> crop.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-template <int MB>
+// SPLIT (the small, K-deep levels: a few hundred output rows, K = 8 x 512): the four waves of a block are the four (kz, ky) tap
+// pairs of ONE unit -- four times the waves, a quarter of the K loop each --, partial sums meet in LDS in a fixed order and wave 0
+// runs the epilogue.  The scalar-weight VALU kernels these levels used were bound by the latency of their scalar loads.
+template <int MB, bool SPLIT>
 __global__ void __launch_bounds__(256)
 icon_up_mfma_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                     const float* __restrict__ wk /*[Cin][64][Cout]*/, const float* __restrict__ bias,
                     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
                     float* __restrict__ out, int Cout, int Dc, int Hc, int Wc, int ntxb, long long nunits) {
+    __shared__ float red[SPLIT ? 3 * MB * 2 * 4 * 64 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long unit = (long long)blockIdx.x * 4 + wave;            // one wave = one (oz, oy, tx block); no barrier in this kernel
-    if (unit >= nunits) return;
+    const long long unit = SPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;   // one wave (SPLIT: one block) = one (oz, oy, tx block)
+    if (unit >= nunits) return;                                          // (SPLIT: block-uniform, so every wave of a live block reaches the barrier)
     const int txb = (int)(unit % ntxb);
     const int rowi = (int)(unit / ntxb);
     const int oy = rowi % Hc, oz = rowi / Hc;
@@ -220,10 +224,10 @@ icon_up_mfma_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
 #pragma unroll
         for (int p = 0; p < 2; ++p) acc[m][p] = f32x4m{0.0f, 0.0f, 0.0f, 0.0f};
     const int tx0 = txb * MB * 16 + col;
-    for (int a = 0; a < 2; ++a) {
+    for (int a = SPLIT ? (wave >> 1) : 0; a < (SPLIT ? (wave >> 1) + 1 : 2); ++a) {
         const int kz = pz ? 2 * a : 1 + 2 * a, iz = pz ? tz + 1 - a : tz - a;          // o = 2 i - 1 + k
         if ((unsigned)iz >= (unsigned)D) continue;
-        for (int b = 0; b < 2; ++b) {
+        for (int b = SPLIT ? (wave & 1) : 0; b < (SPLIT ? (wave & 1) + 1 : 2); ++b) {
             const int ky = py ? 2 * b : 1 + 2 * b, iy = py ? ty + 1 - b : ty - b;
             if ((unsigned)iy >= (unsigned)H) continue;
             const float* xrow = x + ((long long)iz * H + iy) * W;
@@ -253,6 +257,26 @@ icon_up_mfma_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                 }
             }
         }
+    }
+    if constexpr (SPLIT) {
+        if (wave > 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((((wave - 1) * MB + m) * 2 + p) * 4 + r) * 64 + lane] = acc[m][p][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)                                      // fixed order: deterministic
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][p][r] += red[(((w * MB + m) * 2 + p) * 4 + r) * 64 + lane];
     }
     // epilogue: lane = couts co0 + 4 kq + r (r = 0..3) of tx; the two parities are x-adjacent outputs
     int z0, z1, y0, y1;
@@ -483,9 +507,17 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
             const int ntxb = (int)oai::cdiv((dm.d[l][2] + 1) / 2, 16 * MB);
             const long long nunits = (long long)dm.d[l][0] * dm.d[l][1] * ntxb;
             dim3 grid(oai::cdiv(nunits, 4), kUpOut[l] / 16);
-            icon_up_mfma_kernel<MB><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
-                                                          nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
-                                                          dm.d[l][0], dm.d[l][1], dm.d[l][2], ntxb, nunits);
+            icon_up_mfma_kernel<MB, false><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                                 nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                                 dm.d[l][0], dm.d[l][1], dm.d[l][2], ntxb, nunits);
+        } else if (kUpOut[l] % 16 == 0 && kUpIn[l] % 4 == 0) {      // the small, K-deep levels: one block per unit, its waves split the (kz, ky) taps
+            constexpr int MB = 1;
+            const int ntxb = (int)oai::cdiv((dm.d[l][2] + 1) / 2, 16 * MB);
+            const long long nunits = (long long)dm.d[l][0] * dm.d[l][1] * ntxb;
+            dim3 grid((unsigned)nunits, kUpOut[l] / 16);
+            icon_up_mfma_kernel<MB, true><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
+                                                                nw.up_w[l], nw.up_b[l], nw.bn_s[l], nw.bn_t[l], cat[l], kUpOut[l],
+                                                                dm.d[l][0], dm.d[l][1], dm.d[l][2], ntxb, nunits);
         } else if ((long long)oai::cdiv(per_par, 32) * (kUpOut[l] / 16) * 8 >= kFewBlocks) {
             dim3 grid(oai::cdiv(per_par, 32), kUpOut[l] / 16, 8);
             icon_up_kernel<16, 8><<<grid, 256, 0, st>>>(src, kUpIn[l], dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2],
