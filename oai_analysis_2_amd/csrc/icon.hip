@@ -23,6 +23,9 @@ constexpr float kLeaky = 0.01f;
 constexpr float kBnEps = 1e-5f;
 constexpr long long kSplitKBelow = 16384;     // output voxels (per launch / per parity class) below which K is split over threads
 constexpr long long kMfmaUpFrom = 2048;       // output voxels per parity class from which the up-conv runs on MFMA (icon_up_mfma_kernel)
+#ifndef OAI_LAST_XT
+#define OAI_LAST_XT 2
+#endif
 constexpr long long kFewBlocks = 1024;        // split-K launches with fewer workgroups than this use 4 couts per block (4x the blocks)
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.0f ? v : v * kLeaky; }
@@ -313,22 +316,24 @@ icon_up_mfma_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
 }
 
 // lastConv: Conv3d 18 -> 3, k3 p1, / 10, at full resolution.  N = 3 fills no MFMA tile; as a direct VALU convolution the first
-// version did one global load per 3 FMAs.  Here a thread owns 4 x-consecutive voxels x 3 couts: per (ci, dz, dy) it loads the 6
-// inputs x-1 .. x+4 once and does 36 FMAs (weights are wave-uniform scalar loads): 6 x fewer loads per FMA.
+// version did one global load per 3 FMAs.  Here a thread owns XT x-consecutive voxels x 3 couts: per (ci, dz, dy) it loads the XT + 2
+// inputs once and does 9 XT FMAs (weights are wave-uniform scalar loads).  Measured per ICON direction: XT = 8 5.70 ms, 4 5.14 ms,
+// 2 4.85 ms (fewer loads per FMA lose against coalescing and thread count), XT = 1 (round 1) 5.4 ms-equivalent.
+template <int XT>
 __global__ void __launch_bounds__(256)
 icon_last_conv_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                       const float* __restrict__ wk /*[Cin][27][3]*/, const float* __restrict__ bias, float* __restrict__ out, float div) {
-    const int nxq = (W + 3) / 4;
+    const int nxq = (W + XT - 1) / XT;
     const long long total = (long long)D * H * nxq;
     const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= total) return;
     const int xq = (int)(id % nxq);
     const int y = (int)((id / nxq) % H), z = (int)(id / ((long long)nxq * H));
-    const int xs = 4 * xq;
+    const int xs = XT * xq;
     const long long plane = (long long)D * H * W;
-    float acc[4][3];
+    float acc[XT][3];
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < XT; ++v)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[v][j] = 0.0f;
     for (int ci = 0; ci < Cin; ++ci) {
@@ -341,9 +346,9 @@ icon_last_conv_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                 const int iz = z + dz - 1, iy = y + dy - 1;
                 const bool rowok = (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H;
                 const float* rp = xp + ((long long)(rowok ? iz : 0) * H + (rowok ? iy : 0)) * W;
-                float in[6];
+                float in[XT + 2];
 #pragma unroll
-                for (int e = 0; e < 6; ++e) {
+                for (int e = 0; e < XT + 2; ++e) {
                     const int ix = xs - 1 + e;
                     in[e] = rowok && (unsigned)ix < (unsigned)W ? rp[ix] : 0.0f;
                 }
@@ -351,7 +356,7 @@ icon_last_conv_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                 for (int dx = 0; dx < 3; ++dx) {
                     const float* w = wp + ((dz * 3 + dy) * 3 + dx) * 3;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
+                    for (int v = 0; v < XT; ++v)
 #pragma unroll
                         for (int j = 0; j < 3; ++j) acc[v][j] = fmaf(in[v + dx], w[j], acc[v][j]);
                 }
@@ -360,7 +365,7 @@ icon_last_conv_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < XT; ++v)
             if (xs + v < W) {
                 const float r = acc[v][j] + bias[j];
                 out[j * plane + ((long long)z * H + y) * W + xs + v] = div == 1.0f ? r : r / div;
@@ -536,8 +541,9 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
         }
         OAI_CHECK_LAUNCH();
     }
-    icon_last_conv_kernel<<<oai::cdiv((long long)D * H * ((W + 3) / 4), 256), 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W,
-                                                                                           nw.last_w, nw.last_b, out, 10.0f);
+    constexpr int XT = OAI_LAST_XT;
+    icon_last_conv_kernel<XT><<<oai::cdiv((long long)D * H * ((W + XT - 1) / XT), 256), 256, 0, st>>>(cat[0], kUpOut[0] + kDown[0], D, H, W,
+                                                                                                     nw.last_w, nw.last_b, out, 10.0f);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
