@@ -244,6 +244,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="result-preserving tuning option of the fp16x3 path (oai_unet_set_option: sres, sres_mrep, sres_ring, xcd_group); repeatable")
+    ap.add_argument("--no-overlap", action="store_true", help="registration after, not underneath, the segmentation (A/B of VolumePipeline.overlap_registration)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of launcher + collectives, no GPU, no kernels")
     args = ap.parse_args()
 
@@ -293,6 +294,7 @@ def main():
     icon = IconEngine(icon_sd)
     atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
     pipe = VolumePipeline(unet, icon, atlas, batch=args.batch or None)
+    pipe.overlap_registration = not args.no_overlap
     n_distinct = 2
     vols_np = [make_volume((100 * rank if args.mode == "replicas" else 0) + i, VOL_SHAPE) for i in range(n_distinct)]
     vols = [torch.from_numpy(v).cuda() for v in vols_np]                  # resident in HBM before timing

@@ -324,7 +324,10 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
     if (KC == 8 && h->sres) {
-        if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
+        // (diagnostic builds: OAI_ONE_WG=1 asks for 24 KB of unused dynamic LDS, which leaves room for ONE workgroup per CU -- the tap
+        // stream of a wave that has the SIMD to itself, scripts/stamp_phases.py)
+        static const int one_wg = diag_env("OAI_ONE_WG", 0);
+        if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
         else if (h->sres_ring) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else conv3_igemm_sres<2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
     }
