@@ -126,3 +126,38 @@ def test_partition_vote_assemble_matches_reference_golden(golden_dir):
         part = Partition(tuple(int(v) for v in c[f"c{idx}_patch"]), tuple(int(v) for v in c[f"c{idx}_overlap"]))
         tiles = part({"image": c[f"c{idx}_vol"], "name": ""})["image"]
         assert np.array_equal(tiles.cpu().numpy(), c[f"c{idx}_tiles"])
+
+
+def test_dask_task_bodies_with_a_persistent_worker(tmp_path):
+    """dask_processing.py:46-189 -- segment_method / register_images_delayed / deform_probmap_delayed keep their names, arguments and
+    results, but run on ONE resident worker; process_cohort streams a cohort of files through it from a queue."""
+    from oai_analysis_2_amd import dask_processing as dp
+    from oai_analysis_2_amd.io_nifti import write_nifti
+    from oai_analysis_2_amd.registration import DisplacementTransform
+    td = str(tmp_path)
+    _write_models(td, (64, 64, 32), 4)
+    icon_sd = make_icon_state_dict(3, last_scale=0.1)
+    net = (40, 48, 48)
+    dp.set_worker(dp.Worker(models_dir=td, icon_weights=icon_sd, icon_net_shape=net))
+    atlas = Image(make_volume(31, (40, 80, 88)), [0.4, 0.35, 0.75], [0.0, -1.0, 2.0])
+    paths = []
+    for i in range(3):
+        p = os.path.join(td, f"knee{i}.nii.gz")
+        write_nifti(p, Image(make_volume(30 + i, (24, 72, 72)) * 900.0 + 17.0, [0.36, 0.37, 0.7], [1.0, 2.0, 3.0]))   # raw intensities: the window matters
+        paths.append(p)
+    FC, TC = dp.segment_method(paths[0])
+    img0 = dp.image_normalize(dp.readimage(paths[0]), 0.1, 99.9, 0, 1)
+    assert 0.0 <= img0.array.min() and img0.array.max() <= 1.0
+    fc_ref, tc_ref = oseg.segment(img0.array, make_unet_state_dict(4), (64, 64, 32), (16, 16, 8))
+    assert np.abs(FC.array - fc_ref).max() < 1e-5 and np.abs(TC.array - tc_ref).max() < 1e-5
+    phi, A, B = dp.register_images_delayed(paths[0], atlas)
+    assert isinstance(phi, DisplacementTransform) and phi.displacement.shape == (*net, 3) and A.array.max() <= 1.0
+    warped = dp.deform_probmap_delayed(phi, A, B, FC, image_type="FC")
+    assert warped.array.shape == atlas.array.shape
+    seen = {}
+    for i, r in dp.process_cohort(paths, atlas):
+        seen[i] = r
+    assert sorted(seen) == [0, 1, 2]
+    assert np.abs(seen[0].fc.numpy().astype(np.float64) - FC.array).max() < 1e-6                     # the same worker, the same arithmetic
+    assert np.abs(seen[0].fc_atlas.numpy() - warped.array).max() < 1e-4
+    dp.set_worker(None)
