@@ -1,5 +1,7 @@
 #!/bin/bash
 # Diagnostic: per-launch time of the split-resident conv kernel with runtime switches (OAI_DBG bits; results wrong when non-zero).
+# needs the DIAGNOSTIC library (python -m oai_analysis_2_amd.build --diag): the production library ignores OAI_DBG
+export OAI_LIB_PATH=${OAI_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/build/diag/liboai_hip_diag.so}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dbg; mkdir -p $O; cd $R
 export PREC=fp16x3

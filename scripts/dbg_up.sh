@@ -1,5 +1,7 @@
 #!/bin/bash
 # Diagnostic: up-conv kernel time with runtime switches (OAI_DBG 64 = no copy-out stores, 128 = no LDS reads/MFMAs, 256 = no DMA after the prologue, 512 = no epilogue image build)
+# needs the DIAGNOSTIC library (python -m oai_analysis_2_amd.build --diag): the production library ignores OAI_DBG
+export OAI_LIB_PATH=${OAI_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/build/diag/liboai_hip_diag.so}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dbgup; mkdir -p $O; cd $R
 export PREC=fp16x3

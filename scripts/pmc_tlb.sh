@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC: address-translation (UTCL1) and L1 stall counters of the conv kernel, with and without the halo DMA (OAI_DBG=1)
+# needs the DIAGNOSTIC library (python -m oai_analysis_2_amd.build --diag): the production library ignores OAI_DBG
+export OAI_LIB_PATH=${OAI_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/build/diag/liboai_hip_diag.so}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_tlb; mkdir -p $O; cd $R
 export PREC=fp16x3
