@@ -29,7 +29,7 @@ from .image import Image, as_image
 def image_normalize(image, window_min_perc, window_max_perc, output_min, output_max) -> Image:
     """Percentile intensity window -> [output_min, output_max], like the reference; computed on the GPU."""
     img = as_image(image)
-    vol = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32)).cuda()
+    vol = torch.from_numpy(np.array(img.array, dtype=np.float32, order="C", copy=True)).cuda()      # (a file-backed array may be read-only)
     out = ops.image_normalize(vol, window_min_perc, window_max_perc, output_min, output_max)
     return img.like(out.cpu().numpy().astype(img.array.dtype if img.array.dtype.kind == "f" else np.float32))
 
