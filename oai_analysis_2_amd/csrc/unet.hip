@@ -40,6 +40,7 @@ struct oai_unet {
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
     int xcd_group = 32;                 // logical blocks per XCD deal (option "xcd_group"; 0 = launch order)
     bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (option "sres_ring")
+    int fuse_first = 1;                 // ec0 computed inside ec1's halo staging when ec1 is one main-shape launch (option "fuse_first")
     int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (option "sres_mrep" 2|4; 2 runs three workgroups per CU: -2 % on 32 border tiles, +0.5 % on the whole volume)
     bool opt_sres = true;               // option "sres": fp16x3 uses the split-resident kernels
     bool sres = false;                  // fp16x3 runs split-resident (activations stored as fp16 term pairs, unet_sres.h)
@@ -327,7 +328,16 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         // (diagnostic builds: OAI_ONE_WG=1 asks for 24 KB of unused dynamic LDS, which leaves room for ONE workgroup per CU -- the tap
         // stream of a wave that has the SIMD to itself, scripts/stamp_phases.py)
         static const int one_wg = diag_env("OAI_ONE_WG", 0);
-        if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
+        bool done = false;
+        if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
+            if (a.first_w) {                                         // ec0 fused into ec1's halo staging (first_fusable guarantees mrep 4, no strips)
+                conv3_igemm_sres<4, RX, RY, WY, WX, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+                done = true;
+            }
+        }
+        if (done) { }
+        else if (a.first_w) return set_error(OAI_ERR_ARG, "fused ec0 asked of a tile shape that has no such kernel");
+        else if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
         else if (h->sres_ring) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else conv3_igemm_sres<2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
     }
@@ -345,17 +355,41 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
 
 // One conv layer = the main launch over the part of the output box that 8 x 16 (y, x) tiles cover exactly, plus up
 // to two thin remainder strips computed with tile shapes that fit them (trimmed boxes are e.g. 18 x 98 x 98).
+// how launch_conv3 covers a box: ny x nx main (8 x 16) tiles, plus an x strip of wr columns and a y strip of hr rows
+static void strip_plan(const oai_unet* h, const Box& box, int& ny, int& nx, int& hr, int& wr) {
+    const int ry = box.hi[1] - box.lo[1], rx = box.hi[2] - box.lo[2];
+    ny = ry / 8; nx = rx / 16;
+    hr = ry - 8 * ny; wr = rx - 16 * nx;
+    if (h->variant == 2 || ny == 0 || nx == 0) { ny = cdiv(ry, 8); nx = cdiv(rx, 16); hr = wr = 0; }   // no strips
+    if (hr > 4) { ++ny; hr = 0; }            // a tall remainder is cheaper as one more row of main tiles
+    if (wr > 8) { ++nx; wr = 0; }
+}
+
+// ec0 can be computed inside ec1's halo staging (conv3_igemm_sres<..., FIRST>) when ec1 runs as ONE launch of the main shape of the
+// default split-resident kernel and the channel counts are the reference's (1 -> 32 -> ...)
+static bool first_fusable(const oai_unet* h, const Box& ec1_box) {
+    if (!h->sres || !h->fuse_first || h->variant != 0 || h->sres_mrep != 4 || h->sres_ring) return false;
+    if (h->L[EC0].cout != 32 || h->L[EC1].c0 != 32) return false;
+    int ny, nx, hr, wr;
+    strip_plan(h, ec1_box, ny, nx, hr, wr);
+    return hr == 0 && wr == 0;
+}
+
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
                         const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
-                        float* pool_out = nullptr, const ConvArgs* head = nullptr) {
+                        float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr) {
     ConvArgs a;
     if (head) a = *head;                   // the fused dc0 fields (see ConvArgs); everything else is set below
+    if (first) {                           // ec0 fused into this layer's staging (first_fusable)
+        a.first_w = h->L[EC0].plain; a.first_scale = h->L[EC0].scale; a.first_shift = h->L[EC0].shift; a.first_src = *first;
+    }
     a.boxes = boxes;
     a.pool_out = pool_out;
     a.range_flag = h->range_flag;
     { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }      // -DOAI_DIAG builds only; constant 0 otherwise
 #ifdef OAI_DIAG
     a.stamps = diag_stamps();
+    { static const int only = diag_env("OAI_STAMP_LAYER", -1); if (only >= 0 && &L != &h->L[only]) a.stamps = nullptr; }   // one layer's budget (EC1 = 1 ...)
 #endif
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
     a.out = out; a.Cout = L.cout; a.scale = h->precision == OAI_PREC_FP16X3 ? L.scale_f16 : L.scale; a.shift = L.shift;
@@ -366,12 +400,8 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     if (h->sres && (size_t)dims[0] * dims[1] * dims[2] * 64 >= (1ull << 32))       // the staging plan holds 32-bit byte offsets inside a chunk plane
         return set_error(OAI_ERR_ARG, "tile level %dx%dx%d too large for the split-resident kernel (>= 2^26 voxels)", dims[0], dims[1], dims[2]);
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
-    const int ry = box.hi[1] - box.lo[1], rx = box.hi[2] - box.lo[2];
-    int ny = ry / 8, nx = rx / 16;
-    int hr = ry - 8 * ny, wr = rx - 16 * nx;
-    if (h->variant == 2 || ny == 0 || nx == 0) { ny = cdiv(ry, 8); nx = cdiv(rx, 16); hr = wr = 0; }   // no strips
-    if (hr > 4) { ++ny; hr = 0; }            // a tall remainder is cheaper as one more row of main tiles
-    if (wr > 8) { ++nx; wr = 0; }
+    int ny, nx, hr, wr;
+    strip_plan(h, box, ny, nx, hr, wr);
     Box main = box, xs = box, ys = box;
     main.hi[1] = hr ? box.lo[1] + 8 * ny : box.hi[1];
     main.hi[2] = wr ? box.lo[2] + 16 * nx : box.hi[2];
@@ -402,7 +432,7 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.zero = h->zero_rec;
     { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }
 #ifdef OAI_DIAG
-    a.stamps = diag_stamps();
+    a.stamps = diag_env("OAI_STAMP_LAYER", -1) >= 0 ? nullptr : diag_stamps();
 #endif
     const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
     a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
@@ -461,7 +491,9 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     for (int l = 0; l < 4; ++l) { d[l][0] = src.td >> l; d[l][1] = src.th >> l; d[l][2] = src.tw >> l; }
     const size_t v0 = (size_t)src.td * src.th * src.tw;
 
-    {   // ec0 (+ gather)
+    const bool fuse_first = first_fusable(h, need[EC1]);
+    const TileSource* fsrc = fuse_first ? &src : nullptr;
+    if (!fuse_first) {   // ec0 (+ gather)
         dim3 grid(cdiv(v0 / 2, 256), n);
         const int c = L[EC0].cout;
         unsigned char* e0s = reinterpret_cast<unsigned char*>(buf[B_E0]);
@@ -477,9 +509,9 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     int rc;
 #define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
     if (pool_fusable(h, d[0], need[EC1])) {
-        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0]));
+        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0], nullptr, fsrc));
     } else {
-        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1)));
+        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), nullptr, nullptr, fsrc));
         RUN(launch_pool(h, buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
     }
     RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st, tb(EC2)));
@@ -699,6 +731,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: sres_ring must be 0 or 1");
         h->sres_ring = value != 0;
         if (h->sres_ring) h->sres_mrep = 2;
+    } else if (!strcmp(name, "fuse_first")) {
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: fuse_first must be 0 or 1");
+        h->fuse_first = value;
     } else if (!strcmp(name, "xcd_group")) {           // logical blocks per XCD deal; 0 = plain launch order
         OAI_CHECK_ARG(value >= 0 && value <= 4096, "oai_unet_set_option: xcd_group must be in [0, 4096]");
         h->xcd_group = value;

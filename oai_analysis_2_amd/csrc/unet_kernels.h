@@ -43,6 +43,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   reference's fp32 CPU path up to summation order.
 // ---------------------------------------------------------------------------------------------
 
+// Where a tile's input comes from (ec0's gather; also carried by ConvArgs for the ec0-fused ec1 of the split-resident path).
+struct TileSource {
+    const float* vol;        // resident volume [D][H][W]  (or null)
+    const float* tiles;      // explicit tiles [n][td][th][tw] (B3 seam) when vol == null
+    int D, H, W;
+    int td, th, tw;          // tile size
+    int ez, ey, ex;          // effective (kept) size = tile - 2*overlap
+    int oz, oy, ox;          // overlap
+    int gy, gx;              // tile grid (y, x); z-major tile order ind = (i*gy + j)*gx + k
+    int tile_begin;          // global index of local tile 0
+};
+
+__device__ __forceinline__ int reflect_index(int v, int n) {
+    // numpy.pad(mode='reflect'): period 2(n-1), no edge repeat
+    const int p = 2 * (n - 1);
+    int m = v % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - m;
+}
+
 struct ConvArgs {
     const float* src0; const float* src1;   // concat (src0, src1) along channels; src1 may be null
     int C0, C1;
@@ -68,6 +88,11 @@ struct ConvArgs {
     float* head_out = nullptr;               // blocks [tile][ncls][ez][ey][ex]
     int head_ncls = 0, head_mode = 0;        // out_mode of oai_segment_tiles: 0 probability, 1 mask, 2 logit
     int head_k[3] = {0, 0, 0}, head_e[3] = {0, 0, 0};   // origin (in tile coordinates) and extent of a kept-centre block
+    // split-resident kernel only, instantiation FIRST: ec0 (Conv3d 1 -> 32, k3 p1, + ReLU, gather-fused) is computed INTO the halo box
+    // from the raw volume instead of being read back from memory (src0 unused); see conv3_igemm_sres.
+    const float* first_w = nullptr;          // ec0 weights [27][32] (Layer::plain)
+    const float* first_scale = nullptr; const float* first_shift = nullptr;
+    TileSource first_src = {};
 };
 
 // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.  In launch order the cout blocks of one
@@ -702,25 +727,6 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm(const UpArgs a) {
 // ec0: Conv3d(1 -> cout, k3, p1) + ReLU, fused with the overlap-tile gather.  Memory/VALU bound
 // (K = 27): one thread = one voxel x 8 couts, weights through the scalar cache.
 // ---------------------------------------------------------------------------------------------
-
-struct TileSource {
-    const float* vol;        // resident volume [D][H][W]  (or null)
-    const float* tiles;      // explicit tiles [n][td][th][tw] (B3 seam) when vol == null
-    int D, H, W;
-    int td, th, tw;          // tile size
-    int ez, ey, ex;          // effective (kept) size = tile - 2*overlap
-    int oz, oy, ox;          // overlap
-    int gy, gx;              // tile grid (y, x); z-major tile order ind = (i*gy + j)*gx + k
-    int tile_begin;          // global index of local tile 0
-};
-
-__device__ __forceinline__ int reflect_index(int v, int n) {
-    // numpy.pad(mode='reflect'): period 2(n-1), no edge repeat
-    const int p = 2 * (n - 1);
-    int m = v % p;
-    if (m < 0) m += p;
-    return m < n ? m : p - m;
-}
 
 // One thread = two x-adjacent voxels x all 32 (COUT) couts, so every voxel's 128-byte channel row is written
 // whole.  The per-axis neighbour indices (reflect-padded volume index, or -1 for a neighbour outside the TILE =

@@ -108,9 +108,15 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
 // order and touch planes (dz, dz+1), so the planes of chunk c+1 can be DMA'd into the two spare slots and into the slots chunk c
 // frees as it goes -- every plane is requested three dz-phases (~10 us) before its first use, nothing is ever waited for, and
 // the block synchronises once per phase.  Same footprint as the MREP = 4 box (6 x 11.5 KB), two workgroups per CU.
-template <int MREP, int RX, int RY, int WY, int WX, bool RING = false>
+// FIRST (ec1 of the network, Cin = 32 = two chunks): the input of this layer is ec0 = relu(Conv3d(1 -> 32, k3 p1)(tile)), which costs 27
+// FMAs per value.  Instead of a launch that writes it to memory (10.7 GB per 160-tile pass) and a halo box that reads it back by
+// LDS-DMA (2.1 x that, HBM-latency misses that occupy the CU's L1 in front of the epilogue's stores), the block stages the raw
+// (HZ+2) x (HY+2) x (HX+2) patch of the volume once (7.7 KB, gathered with the reflect padding of Partition.__call__) and every
+// thread computes its halo records on the VALU -- the same fmaf chain, scale/shift, ReLU and split as conv3_first_sres_kernel, so the
+// records are bit-identical to the ones that kernel writes -- while the partner workgroup of the CU owns the matrix pipe.
+template <int MREP, int RX, int RY, int WY, int WX, bool RING = false, bool FIRST = false>
 __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
-    static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4) && (!RING || MREP == 2), "bad tile shape");
+    static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4) && (!RING || MREP == 2) && (!FIRST || !RING), "bad tile shape");
     constexpr int NREP = 2, TZ = MREP;
     constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2, HZ = TZ + 2;
     constexpr int HVOX = HZ * HY * HX;
@@ -120,6 +126,9 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     constexpr int PLB = NITP * 256 * 16;                         // RING: bytes of one plane slot (whole 1-KiB wave writes)
     constexpr int BUF = RING ? 6 * PLB : NIT * 256 * 16;         // bytes
     __shared__ __attribute__((aligned(16))) unsigned char lds[BUF];
+    constexpr int PZ = HZ + 2, PY = HY + 2, PX = HX + 2;         // FIRST: raw patch = halo box + ec0's own halo
+    __shared__ float raw[FIRST ? PZ * PY * PX : 1];
+    __shared__ int rawidx[FIRST ? PZ + PY + PX : 1];             // per-axis source offsets (reflect-padded volume index) or -1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     unsigned poff[NIT];
     const int pslot = tid & 3;       // LDS slot position of this thread's pieces (P = it*256 + tid, so P & 3 = tid & 3)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < (FIRST ? 0 : NIT); ++it) {
         const int r = (it * 256 + tid) >> 2;
         const int hx = r % HX, t2 = r / HX, hy = t2 % HY, hz = t2 / HY;
         const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
@@ -201,6 +210,144 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds + (it * 256 + wave * 64) * 16), 16, 0, 0);     // cache-policy bits sc0 / sc1 / nt on the DMA: measured, no effect (profiles/r02_conv_phases.md)
         }
+    };
+
+    // ---- FIRST: the raw patch, then ec0 on the VALU straight into the halo box (chunk ch = ec0 channels [16 ch, 16 ch + 16))
+    int first_bad = 0;
+    if constexpr (FIRST) {
+        const TileSource& s = a.first_src;
+        if (tid < PZ + PY + PX) {
+            const int ax = tid < PZ ? 0 : tid < PZ + PY ? 1 : 2;
+            const int p = tid - (ax == 0 ? 0 : ax == 1 ? PZ : PZ + PY);
+            const int c = (ax == 0 ? oz0 : ax == 1 ? oy0 : ox0) - 2 + p;                   // tile coordinate
+            const int tdim = ax == 0 ? s.td : ax == 1 ? s.th : s.tw;
+            int v = -1;
+            if ((unsigned)c < (unsigned)tdim) {                                               // outside the tile: Conv3d's zero padding
+                if (s.vol) {
+                    const int t = s.tile_begin + tile;
+                    const int tk = t % s.gx, tj = (t / s.gx) % s.gy, ti = t / (s.gx * s.gy);
+                    v = ax == 0 ? reflect_index(ti * s.ez + c - s.oz, s.D) * s.H * s.W
+                      : ax == 1 ? reflect_index(tj * s.ey + c - s.oy, s.H) * s.W : reflect_index(tk * s.ex + c - s.ox, s.W);
+                } else v = ax == 0 ? c * s.th * s.tw : ax == 1 ? c * s.tw : c;
+            }
+            rawidx[tid] = v;
+        }
+        __syncthreads();
+        const float* base = s.vol ? s.vol : s.tiles + (size_t)tile * s.td * s.th * s.tw;
+        constexpr int RIT = (PZ * PY * PX + 255) / 256;
+        float rv[RIT];                                                                        // all gathers in flight before the first LDS write
+#pragma unroll
+        for (int k = 0; k < RIT; ++k) {
+            const int i = min(k * 256 + tid, PZ * PY * PX - 1);
+            const int px = i % PX, t2 = i / PX, py = t2 % PY, pz = t2 / PY;
+            const int iz = rawidx[pz], iy = rawidx[PZ + py], ix = rawidx[PZ + PY + px];
+            rv[k] = (iz | iy | ix) >= 0 ? base[(size_t)iz + iy + ix] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < RIT; ++k)
+            if (k * 256 + tid < PZ * PY * PX) raw[k * 256 + tid] = rv[k];                     // (visible behind the chunk loop's first barrier)
+    }
+    // ec0 for V halo voxels of this thread at a time (records r = (j0 + v) * 256 + tid): every 16 weights of a tap are fetched once
+    // (one s_load_dwordx16) for V x 16 FMAs, so the scalar-cache latency hides behind them; V = 2 is what the registers next to the
+    // 128 accumulators allow.
+    auto first_group = [&](auto vtag, int j0, int ch) __attribute__((always_inline)) {
+        constexpr int V = decltype(vtag)::value;
+        // [27][32] weights, scale, shift: wave-uniform addresses.  Read through the constant address space so that they become scalar
+        // loads (SGPR operands of v_fmac): behind a barrier hipcc otherwise picks per-lane global loads.
+        typedef const __attribute__((address_space(4))) float* cptr;
+        const float* wg = a.first_w + ch * 16;
+        asm volatile("" : "+s"(wg));          // an opaque copy per group: hipcc otherwise keeps the first group's 432 weights for the later groups, in VGPR lanes (v_readlane per FMA)
+        const cptr w = (cptr)wg, fsc = (cptr)(a.first_scale + ch * 16), fsh = (cptr)(a.first_shift + ch * 16);
+        int r[V], hx[V];
+        bool ok[V], inside[V];
+        const float* rp[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            r[v] = (j0 + v) * 256 + tid;
+            ok[v] = r[v] < HVOX;
+            const int rr = ok[v] ? r[v] : 0;
+            hx[v] = rr % HX;
+            const int t2 = rr / HX, hy = t2 % HY, hz = t2 / HY;
+            rp[v] = raw + (hz * PY + hy) * PX + hx[v];
+            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx[v];
+            inside[v] = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        }
+        float e[V][16];
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) e[v][c] = 0.0f;
+        // Tap order of conv3_first_sres_kernel: (dz, dy) outer, dx inner.  Hand-placed prefetch: the 16 weights (one s_load_dwordx16) and
+        // the V inputs (LDS) of tap t+1 are requested BEHIND the first FMAs of tap t -- i.e. behind the wait for tap t's operands, scalar
+        // loads return out of order so every wait is lgkmcnt(0) -- and have the other 15 V FMAs of tap t to arrive.  (Left to itself the
+        // scheduler hoists all 27 s_loads to the top, runs out of SGPRs and parks the weights in VGPR lanes: a v_readlane per FMA.)
+        float wc[16], inc[V];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wc[c] = w[c];
+#pragma unroll
+        for (int v = 0; v < V; ++v) inc[v] = rp[v][0];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            float wn[16], inn[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) e[v][0] = fmaf(inc[v], wc[0], e[v][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 27) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) wn[c] = w[(t + 1) * 32 + c];
+#pragma unroll
+                for (int v = 0; v < V; ++v) inn[v] = rp[v][(((t + 1) / 9) * PY + ((t + 1) / 3) % 3) * PX + (t + 1) % 3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 1; c < 16; ++c)
+#pragma unroll
+                for (int v = 0; v < V; ++v) e[v][c] = fmaf(inc[v], wc[c], e[v][c]);
+            __builtin_amdgcn_sched_barrier(0);
+            // pin the tap: without a chained use the instruction selector's linearisation moves a whole voxel's FMA chain behind the other's
+            // (sched_barrier orders only what has a chain), keeping 27 inputs in VGPRs and all 432 weights in VGPR lanes for it
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                asm volatile("" : "+v"(e[v][0]), "+v"(e[v][1]), "+v"(e[v][2]), "+v"(e[v][3]), "+v"(e[v][4]), "+v"(e[v][5]), "+v"(e[v][6]), "+v"(e[v][7]),
+                                  "+v"(e[v][8]), "+v"(e[v][9]), "+v"(e[v][10]), "+v"(e[v][11]), "+v"(e[v][12]), "+v"(e[v][13]), "+v"(e[v][14]), "+v"(e[v][15]));
+            if (t + 1 < 27) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) wc[c] = wn[c];
+#pragma unroll
+                for (int v = 0; v < V; ++v) inc[v] = inn[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            u16x8 hi[2], lo[2];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float x = e[v][c] * fsc[c] + fsh[c];
+                x = fmaxf(x, 0.0f);
+                if (!inside[v]) x = 0.0f;                                                     // ec1's own zero padding at the tile border
+                first_bad |= !(fabsf(x) <= 65504.0f);
+                unsigned l;
+                hi[c >> 3][c & 7] = (unsigned short)split2_f16(x, l);
+                lo[c >> 3][c & 7] = (unsigned short)l;
+            }
+            if (ok[v]) {
+                unsigned char* rec = lds + r[v] * 64;
+                const int key = (hx[v] >> 2) & 3;                                             // logical slot s lives at position s ^ key
+                *reinterpret_cast<u16x8*>(rec + ((0 ^ key) << 4)) = hi[0];
+                *reinterpret_cast<u16x8*>(rec + ((1 ^ key) << 4)) = hi[1];
+                *reinterpret_cast<u16x8*>(rec + ((2 ^ key) << 4)) = lo[0];
+                *reinterpret_cast<u16x8*>(rec + ((3 ^ key) << 4)) = lo[1];
+            }
+        }
+    };
+    auto stage_first = [&](int ch) __attribute__((always_inline)) {
+        static_assert(!FIRST || (HVOX > 4 * 256 && HVOX <= 4 * 256 + 64), "the voxel grouping below is for the 6 x 10 x 18 halo box");
+        // 2 + 2 (+ 1 in wave 0: records 1024 .. 1079).  A 3 + 2 grouping was measured slower (176.1 vs 173.9 ms per volume): its record
+        // addresses spill to scratch around the groups.
+#pragma unroll 1
+        for (int j0 = 0; j0 < 4; j0 += 2) first_group(std::integral_constant<int, 2>{}, j0, ch);
+        if (wave == 0) first_group(std::integral_constant<int, 1>{}, 4, ch);
+        // (an if / else over a <2> and a <1> group made hipcc hoist all 432 weight loads above the branch and spill them to VGPR lanes)
     };
 
     // ---- RING staging plan: this thread's NITP pieces of each of the chunk's four z planes
@@ -324,7 +471,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 OAI_STAMP(0);
                 __syncthreads();                                             // every wave is done reading the previous chunk
                 OAI_STAMP(1);
-                if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
+                if constexpr (FIRST) { if (!OAI_DBG_BIT(a, 4)) stage_first(ch); }
+                else if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
                 OAI_STAMP(2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
                 OAI_STAMP(3);
@@ -363,7 +511,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             }
         };
         const int ml = m_lo == 0 ? m_hi : MREP;                         // workgroup-uniform
-        if constexpr (MREP == 4) {
+        if constexpr (FIRST) run_chunks(std::integral_constant<int, MREP>{});       // (one copy of the inlined ec0 code; dead slices are never stored)
+        else if constexpr (MREP == 4) {
             if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
             else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
             else if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
@@ -386,7 +535,9 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int nco = (a.Cout + 15) / 16;                               // chunks of the output tensor
     float vmax = 0.0f;
-    const bool head = a.head_w != nullptr;                            // uniform; host guarantees ncb == 1 and head_ncls <= 4
+    const bool head = !FIRST && a.head_w != nullptr;                  // uniform; host guarantees ncb == 1 and head_ncls <= 4
+    typedef const __attribute__((address_space(4))) float* cfptr;     // wave-uniform reads -> scalar loads (see stage_first)
+    const cfptr head_w = (cfptr)a.head_w;
     constexpr int HV = TV / 256;                                      // block voxels per thread in the fused dc0
     float hacc[HV][4];
 #pragma unroll
@@ -451,7 +602,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                                 const float xv = join2_f16(hi[e], lo[e]);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k)
-                                    if (k < a.head_ncls) hacc[j][k] = fmaf(xv, a.head_w[k * a.Cout + c], hacc[j][k]);
+                                    if (k < a.head_ncls) hacc[j][k] = fmaf(xv, head_w[k * a.Cout + c], hacc[j][k]);
                             }
                         }
                     }
@@ -521,7 +672,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             }
         }
     }
-    if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);           // fp16 cannot hold it: report, never silently inf
+    if (!(vmax <= 65504.0f) || first_bad) atomicOr(a.range_flag, 1);           // fp16 cannot hold it: report, never silently inf
 #ifdef OAI_DIAG
     OAI_STAMP(6);
     OAI_STAMPB(6);

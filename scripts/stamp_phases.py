@@ -9,6 +9,8 @@ from oai_analysis_2_amd.segmentation.engine import UNetEngine
 lib = C.CDLL(_lib.LIB_PATH)
 eng = UNetEngine(make_unet_state_dict(0), precision="fp16x3")
 vol = torch.from_numpy(make_volume(0)).cuda()
+for kv in os.environ.get("OPTIONS", "").split(","):          # e.g. OPTIONS=fuse_first=0; OAI_STAMP_LAYER=<layer index> (ec1 = 1) stamps one layer only
+    if kv: eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 SET = int(os.environ.get("STAMP_SET", "0"))      # must match the -DOAI_STAMP_SET the diagnostic library was built with
 names = ({0: "loop->bar1", 1: "barrier 1", 2: "DMA issue", 3: "DMA wait", 4: "barrier 2", 5: "27 taps", 6: "epilogue", 7: "prologue"} if SET == 0 else
          {0: "last tap -> 1st epilogue barrier", 1: "split + LDS image", 2: "barriers", 3: "copy-out stores", 4: "fused dc0 dots", 5: "fused pool stores",
