@@ -40,6 +40,7 @@ struct oai_unet {
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
     int xcd_group = 32;                 // logical blocks per XCD deal (option "xcd_group"; 0 = launch order)
     bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (option "sres_ring")
+    int b_lds = 0;                      // weight fragments through a three-slot LDS ring shared by the workgroup (option "b_lds")
     int fuse_first = 1;                 // ec0 computed inside ec1's halo staging when ec1 is one main-shape launch (option "fuse_first")
     int sres_mrep = 4;                  // z slices per block of the split-resident conv kernel (option "sres_mrep" 2|4; 2 runs three workgroups per CU: -2 % on 32 border tiles, +0.5 % on the whole volume)
     bool opt_sres = true;               // option "sres": fp16x3 uses the split-resident kernels
@@ -337,6 +338,7 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         }
         if (done) { }
         else if (a.first_w) return set_error(OAI_ERR_ARG, "fused ec0 asked of a tile shape that has no such kernel");
+        else if (h->sres_mrep == 4 && h->b_lds) conv3_igemm_sres<4, RX, RY, WY, WX, false, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
         else if (h->sres_ring) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else conv3_igemm_sres<2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
@@ -432,7 +434,8 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.zero = h->zero_rec;
     { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }
 #ifdef OAI_DIAG
-    a.stamps = diag_env("OAI_STAMP_LAYER", -1) >= 0 ? nullptr : diag_stamps();
+    a.stamps = diag_stamps();
+    { static const int only = diag_env("OAI_STAMP_LAYER", -1); if (only >= 0 && &L != &h->L[only]) a.stamps = nullptr; }   // DC9 = 8, DC6 = 11, DC3 = 14
 #endif
     const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
     a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
@@ -731,6 +734,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: sres_ring must be 0 or 1");
         h->sres_ring = value != 0;
         if (h->sres_ring) h->sres_mrep = 2;
+    } else if (!strcmp(name, "b_lds")) {
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: b_lds must be 0 or 1");
+        h->b_lds = value;
     } else if (!strcmp(name, "fuse_first")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: fuse_first must be 0 or 1");
         h->fuse_first = value;

@@ -79,6 +79,21 @@ __device__ __forceinline__ void split_two_voxels(float vA, float vB, unsigned se
     w_lo = __builtin_amdgcn_perm(PL, L, sel);
 }
 
+// One LDS-DMA piece (global_load_lds_dwordx4: lane l moves 16 bytes from its global address to LDS byte lds_addr + 16 l; lds_addr is
+// wave-uniform) as inline assembly.  Why not the builtin: the compiler's wait-count pass treats every LDS-DMA as a store to ALL of LDS and
+// puts `s_waitcnt vmcnt(0)` in front of the next LDS read -- also when that read is from another ring slot -- and __syncthreads() drains
+// vmcnt as well: a "three-stage ring" built from the builtin waits for the piece it has just requested (the up-conv's k loop spent
+// ~10 k cycles per step that way).  Through the asm the pass sees no LDS-DMA; the counted waits are written by hand next to the barrier.
+// M0 is saved and restored so that the compiler's own view of it (it sets M0 for the builtin form elsewhere) stays true.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr /* wave-uniform; an SGPR */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {      // LDS byte address of a __shared__ object
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 // ---- converters (bring-up / B3 seam only): fp32 channels-last <-> format S ------------------------------------------------
 __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, size_t nvox, int C) {
     const int nch = (C + 15) / 16;
@@ -114,9 +129,14 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
 // (HZ+2) x (HY+2) x (HX+2) patch of the volume once (7.7 KB, gathered with the reflect padding of Partition.__call__) and every
 // thread computes its halo records on the VALU -- the same fmaf chain, scale/shift, ReLU and split as conv3_first_sres_kernel, so the
 // records are bit-identical to the ones that kernel writes -- while the partner workgroup of the CU owns the matrix pipe.
-template <int MREP, int RX, int RY, int WY, int WX, bool RING = false, bool FIRST = false>
+// BLDS (MREP 4, not FIRST / RING): the weight fragments of a tap -- the same 4 KiB for the four waves of the workgroup, which today each
+// fetch all of it through the CU's L1, in order behind the halo misses and the partner's stores -- go through a three-slot LDS ring:
+// every wave LDS-DMAs one KiB of the slab two taps ahead, one s_barrier per tap publishes it, and the fragments are read from LDS one tap
+// ahead.  12 KB on top of the 68 KB halo box: two workgroups fill the CU's 160 KB exactly.
+template <int MREP, int RX, int RY, int WY, int WX, bool RING = false, bool FIRST = false, bool BLDS = false>
 __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4) && (!RING || MREP == 2) && (!FIRST || !RING), "bad tile shape");
+    static_assert(!BLDS || (MREP == 4 && !RING && !FIRST), "the weight ring is for the default kernel");
     constexpr int NREP = 2, TZ = MREP;
     constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2, HZ = TZ + 2;
     constexpr int HVOX = HZ * HY * HX;
@@ -126,6 +146,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     constexpr int PLB = NITP * 256 * 16;                         // RING: bytes of one plane slot (whole 1-KiB wave writes)
     constexpr int BUF = RING ? 6 * PLB : NIT * 256 * 16;         // bytes
     __shared__ __attribute__((aligned(16))) unsigned char lds[BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char blds[BLDS ? 3 * 4096 : 16];     // BLDS: weight slabs of taps g, g+1, g+2 (slot = tap % 3)
     constexpr int PZ = HZ + 2, PY = HY + 2, PX = HX + 2;         // FIRST: raw patch = halo box + ec0's own halo
     __shared__ float raw[FIRST ? PZ * PY * PX : 1];
     __shared__ int rawidx[FIRST ? PZ + PY + PX : 1];             // per-axis source offsets (reflect-padded volume index) or -1
@@ -388,11 +409,30 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     constexpr int STEP = 2 * NREP * 64;                             // 16-byte units of weights per tap: [term][nr][lane]
     const float4* wp = a.wpanel + (size_t)cb * nchunks * 27 * STEP + lane;
     float4 bcur[2][NREP], bnext[2][NREP];
+    // BLDS: this lane's 16 bytes of the slab this wave copies (wave w moves bytes [1024 w, 1024 w + 1024) of every slab); `gleft` = slabs
+    // not yet requested (the pointer sticks to the last slab when they run out, so that every tap issues exactly one piece)
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(a.wpanel + (size_t)cb * nchunks * 27 * STEP) + wave * 1024 + lane * 16;
+    int gleft = nchunks * 27;
+    const unsigned bl_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(blds) + wave * 1024);
+    auto issue_b = [&](int slot) __attribute__((always_inline)) {
+        lds_dma16(bsrc, bl_addr + slot * 4096);               // (asm form: no compiler-made vmcnt(0) in front of the next LDS read, see lds_dma16)
+        if (--gleft > 0) bsrc += 4096;
+    };
+    auto read_b = [&](float4 (&dst)[2][NREP], int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) bcur[k][n] = wp[(k * NREP + n) * 64];
-    wp += STEP;
+            for (int n = 0; n < NREP; ++n) dst[k][n] = *reinterpret_cast<const float4*>(blds + slot * 4096 + ((k * NREP + n) * 64 + lane) * 16);
+    };
+    if constexpr (BLDS) {
+        issue_b(0); issue_b(1); issue_b(2);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bcur[k][n] = wp[(k * NREP + n) * 64];
+        wp += STEP;
+    }
 
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
     float4 acur[2][MREP];           // (a register prefetch of the next tap's A fragments was measured: no gain, and it costs MREP 2 its third workgroup per CU)
@@ -478,15 +518,29 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 OAI_STAMP(3);
                 __syncthreads();                                             // ... and everybody else's
                 OAI_STAMP(4);
+                if constexpr (BLDS) { if (ch == 0) read_b(bcur, 0); }           // slab 0 (landed with the halo, behind the barrier above)
                 load_a(acur[0], 0, 0);
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
+                    if constexpr (BLDS) {
+                        // in flight: the slabs of taps t+1 (requested two taps ago) and t+2: the older one has landed -- for everybody behind
+                        // the barrier, which also says that everybody has read slab t (slot t % 3) into registers: it is refilled with t+3
+                        if (t > 0 || ch == 0) {          // (tap 0 stands right behind the chunk's own barrier -- except in chunk 0, where slab 0 has just been read from the slot refilled below)
+                            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                        }
+                        issue_b(t % 3);
+                        read_b(bnext, (t + 1) % 3);
+                    }
                     load_a(acur[1], t, 1);
+                    if constexpr (!BLDS) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
+                        for (int k = 0; k < 2; ++k)
 #pragma unroll
-                        for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
-                    if (!OAI_DBG_BIT(a, 2)) wp += STEP;
+                            for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
+                        if (!OAI_DBG_BIT(a, 2)) wp += STEP;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int p = 0; p < 2; ++p)                              // a0.b0, a0.b1
@@ -760,16 +814,15 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         bsrc[g] = nb * 4 + g < ngroups ? reinterpret_cast<const unsigned char*>(a.wpanel + (size_t)(nb * 4 + g) * nks * 4 * 64) + tid * 16 : nullptr;
+    const unsigned ring_addr = lds_addr_of(ulds);
     auto issue = [&](int st, int ks) {
-        unsigned char* base = ulds + st * kStage + wave * 1024;
+        const unsigned base = __builtin_amdgcn_readfirstlane(ring_addr + st * kStage + wave * 1024);
 #pragma unroll
         for (int it = 0; it < 2; ++it)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[it] ? asrc[it] + (size_t)ks * plane * 64 : a.zero),
-                                             (__attribute__((address_space(3))) void*)(base + it * 4096), 16, 0, 0);
+            lds_dma16(asrc[it] ? asrc[it] + (size_t)ks * plane * 64 : a.zero, base + it * 4096);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[g] ? bsrc[g] + (size_t)ks * 4096 : a.zero),
-                                             (__attribute__((address_space(3))) void*)(base + 8192 + g * 4096), 16, 0, 0);
+            lds_dma16(bsrc[g] ? bsrc[g] + (size_t)ks * 4096 : a.zero, base + 8192 + g * 4096);
     };
     f32x16 acc[2][4];
 #pragma unroll
@@ -792,9 +845,11 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
     if (nks > 1) issue(1, 1);
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
     for (int ks = 0; ks < nks; ++ks) {
-        if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage ks landed; the younger stage may still fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                   // everybody's pieces of stage ks are in; stage ks-1 is read out
+        // stage ks has landed (the younger stage's six pieces may still fly) and this wave's LDS reads of stage ks-1 are done ...
+        if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // ... for everybody (a bare barrier: __syncthreads() would drain vmcnt)
+        asm volatile("" ::: "memory");
         if (ks + 2 < nks && !OAI_DBG_BIT(a, 256)) issue((ks + 2) % 3, ks + 2);
         if (active && !OAI_DBG_BIT(a, 128)) {
             const unsigned char* sp = ulds + (ks % 3) * kStage;

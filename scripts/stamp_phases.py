@@ -25,8 +25,8 @@ for tiles in (32, 160):
     lib.oai_diag_stamps(out, 1)
     waves, chunks = out[8], out[9]
     tot = sum(out[i] for i in names)
-    print(f"{tiles} tiles: {waves} waves, {chunks} wave-chunks, {tot / waves:.0f} cycles per wave")
-    for i, n in names.items():
+    print(f"{tiles} tiles: {waves} waves, {chunks} wave-chunks, {tot / max(waves, 1):.0f} cycles per wave")
+    for i, n in (names.items() if waves else ()):
         per_chunk = SET == 0 and i < 6
         per = out[i] / (chunks if per_chunk else waves)
         print(f"   {n:34s} {100 * out[i] / tot:5.1f} %   {per:9.0f} cycles per {'chunk' if per_chunk else 'block'}")
