@@ -21,9 +21,10 @@ def load(path, name):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
 f = load(find("fetch", "counter_collection.csv"), "FETCH_SIZE"); w = load(find("write", "counter_collection.csv"), "WRITE_SIZE")
-def warm(rows):                                       # second (warm) 32-tile pass = from the last first-conv launch on
-    i = max(k for k, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"])
-    return rows[i:]
+def warm(rows):                                       # second (warm) 32-tile pass = from its first launch on: ec0, or the ec0-fused ec1 (<..., false, true, false>)
+    first = [k for k, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"]] or \
+            [k for k, r in enumerate(rows) if "conv3_igemm_sres" in r["Kernel_Name"] and "false, true, false>" in r["Kernel_Name"]]
+    return rows[max(first):]
 f = warm(f); w = warm(w)
 lines = ["| kernel (dispatch order, warm 32-tile pass) | FETCH raw MiB | FETCH x2 MiB | WRITE MiB |", "|---|---|---|---|"]
 tot = {"conv_f": 0.0, "conv_w": 0.0, "conv_n": 0, "all_f": 0.0, "all_w": 0.0}
