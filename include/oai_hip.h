@@ -172,6 +172,8 @@ int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream);
  *   "sres_mrep" 2|4 (4) z slices per workgroup of the split-resident conv kernel
  *   "sres_ring" 0|1 (0) six-slot z-plane ring staging (implies sres_mrep 2)
  *   "xcd_group" n (32)  logical blocks dealt to one XCD at a time; 0 = plain launch order
+ *   "fuse_first" 0|1 (1) ec0 (networks.py:43) computed inside ec1's halo staging instead of as its own launch (when ec1 is one main-shape launch)
+ *   "b_lds" 0|1 (0)     conv weight fragments through a three-slot LDS ring shared by the four waves of a workgroup
  * Unknown names and out-of-range values return OAI_ERR_ARG. */
 int oai_unet_set_option(oai_unet* h, const char* name, int value);
 

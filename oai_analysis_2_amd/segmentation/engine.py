@@ -123,7 +123,7 @@ class UNetEngine:
         return n
 
     def set_option(self, name: str, value: int) -> None:
-        """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group": include/oai_hip.h)."""
+        """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds": include/oai_hip.h)."""
         _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
 
     def range_overflow(self, reset: bool = True) -> bool:
