@@ -57,3 +57,28 @@ def test_argument_checks_of_the_later_entry_points():
     assert lib.oai_stitch_blocks(dummy, 2, 16, 16, 16, t, o, None, dummy, None) != 0 and b"overlap" in lib.oai_last_error()
     assert lib.oai_unet_set_precision(None, 3) != 0
     assert lib.oai_image_normalize(None, 10, 0.1, 99.9, 0.0, 1.0, None, None, None, 0, None) != 0
+
+
+def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
+    """Code-object checks of the shipped library (no GPU needed): (a) no packed fp32 VALU instruction anywhere -- round 2 measured
+    v_pk_fma_f32 / v_pk_mul_f32 returning wrong values in 16-lane groups when a kernel runs beside the MFMA kernels
+    (profiles/r02_packed_fp32_hazard.md; build.py turns the feature off); (b) the hot kernels are what DESIGN.md says: 3-pass fp16
+    MFMAs fed by LDS-DMA in the conv, fp32 MFMAs in the exact path."""
+    import glob
+    import shutil
+    import subprocess
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("no llvm-objdump in this image")
+    path = build.build_library(verbose=False)
+    work = str(tmp_path)
+    shutil.copy(path, os.path.join(work, "lib.so"))
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)      # extracts the bundles next to the copy
+    objs = glob.glob(os.path.join(work, "lib.so.*gfx950*"))
+    assert objs, "no gfx950 code object in the library"
+    text = "".join(subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout for o in objs)
+    packed = re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", text)
+    assert not packed, f"{len(packed)} packed fp32 VALU instructions in the library"
+    assert text.count("v_mfma_f32_32x32x16_f16") > 5000 and text.count("v_mfma_f32_32x32x2_f32") > 1000
+    assert text.count("global_load_lds_dwordx4") > 100
