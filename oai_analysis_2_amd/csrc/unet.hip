@@ -447,7 +447,15 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.nmb = cdiv(nvox, split && h->sres ? 128 : 64);       // voxels per workgroup: 128 in the split-resident kernel
     a.nnb = cdiv(8 * L.cout, 256);
     a.relu = 1;
-    if (split && h->sres) upconv2_igemm_sres<<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
+    if (split && h->sres) {
+        unsigned grid = (unsigned)((size_t)ntiles * a.nmb * a.nnb);
+        if (h->xcd_group > 0) {                               // same dealing as the conv kernel's (launch_conv3_shape)
+            a.nblocks = (int)grid; a.xcd_group = h->xcd_group;
+            const unsigned q = 8u * (unsigned)h->xcd_group;
+            grid = (grid + q - 1) / q * q;
+        }
+        upconv2_igemm_sres<<<grid, 256, 0, st>>>(a);
+    }
     else if (split) upconv2_igemm<true><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
     else upconv2_igemm<false><<<(unsigned)((size_t)ntiles * a.nmb * a.nnb), 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();

@@ -535,6 +535,8 @@ struct UpArgs {
     const unsigned char* zero = nullptr; // split-resident kernel: 64 zero bytes, the LDS-DMA source of rows / columns that do not exist
     unsigned long long* stamps = nullptr;   // -DOAI_DIAG builds: phase cycle sums of the up-conv kernel at stamps[16..31]
     int dbg = 0;                        // diagnostic timing switches (OAI_DBG bits 64/128/256/512; results wrong when set)
+    int nblocks = 0, xcd_group = 0;     // split-resident kernel: true workgroup count and the XCD dealing granularity (xcd_block_id): the column
+                                        // blocks of one row block read the same A rows and should meet in one L2
 };
 
 // SPLIT = false: exact fp32 MFMA.  SPLIT = true: split-fp16, 3 passes (see conv3_igemm_bf16s): the A rows are split in

@@ -765,7 +765,8 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char ulds[kRing + 512];          // ring (the 64-KB epilogue image reuses it) + voxel table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int id = blockIdx.x;
+    int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
+    if (id < 0) return;
     const int nb = id % a.nnb; id /= a.nnb;
     const int mb = id % a.nmb; id /= a.nmb;
     const int tile = id;
