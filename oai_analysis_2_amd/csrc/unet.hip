@@ -399,8 +399,8 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
     a.ncb = (L.cout + 63) / 64;
     a.relu = 1;
-    if (h->sres && (size_t)dims[0] * dims[1] * dims[2] * 64 >= (1ull << 32))       // the staging plan holds 32-bit byte offsets inside a chunk plane
-        return set_error(OAI_ERR_ARG, "tile level %dx%dx%d too large for the split-resident kernel (>= 2^26 voxels)", dims[0], dims[1], dims[2]);
+    if (h->sres && (size_t)dims[0] * dims[1] * dims[2] * 128 >= (1ull << 32))      // staging plan and copy-out hold 32-bit byte offsets inside one / two chunk planes
+        return set_error(OAI_ERR_ARG, "tile level %dx%dx%d too large for the split-resident kernel (>= 2^25 voxels)", dims[0], dims[1], dims[2]);
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
     int ny, nx, hr, wr;
     strip_plan(h, box, ny, nx, hr, wr);

@@ -591,18 +591,28 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     float vmax = 0.0f;
     const bool head = !FIRST && a.head_w != nullptr;                  // uniform; host guarantees ncb == 1 and head_ncls <= 4
     typedef const __attribute__((address_space(4))) float* cfptr;     // wave-uniform reads -> scalar loads (see stage_first)
-    const cfptr head_w = (cfptr)a.head_w;
+    const cfptr head_w = (cfptr)a.head_w, head_b = (cfptr)a.head_b;     // (head_b as a per-lane load sat, with its vmcnt(0), in front of every head store)
     constexpr int HV = TV / 256;                                      // block voxels per thread in the fused dc0
     float hacc[HV][4];
 #pragma unroll
     for (int j = 0; j < HV; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) hacc[j][k] = 0.0f;
+    // this lane's column scales / shifts of both cout halves, loaded and WAITED FOR once, here: loaded inside the loop, the second half's
+    // pair is waited for with vmcnt(0) behind the first half's copy-out stores, i.e. until those have reached memory
+    float scv[NREP], shv[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = cb * 64 + n * 32 + row;
+        scv[n] = co < a.Cout ? a.scale[co] : 0.0f; shv[n] = co < a.Cout ? a.shift[co] : 0.0f;
+    }
+    static_assert(NREP == 2, "the operand list below names both halves");
+    asm volatile("" : "+v"(scv[0]), "+v"(scv[1]), "+v"(shv[0]), "+v"(shv[1]));
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
         const bool cvalid = co < nco * 16;                            // padded channels of the last chunk are written as 0
-        const float sc = co < a.Cout ? a.scale[co] : 0.0f, sh = co < a.Cout ? a.shift[co] : 0.0f;
+        const float sc = scv[n], sh = shv[n];
         const bool odd = row & 1;
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         unsigned char* lrow = lds + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
@@ -662,15 +672,30 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                     }
             }
         } else if (!OAI_DBG_BIT(a, 16)) {
+            // Piece sidx = it*256 + tid of the image = 16 bytes (q & 3) of the record (chunk q >> 2) of block voxel w = it*32 + (tid >> 3).
+            // kTX * kTY = 128, so z = it >> 2 and the (y, x) of w split into a per-LANE part (from tid >> 3 < 32) and a per-ITERATION part (from
+            // (it & 3) * 32): the destination is one per-lane 32-bit offset (computed once) + a wave-uniform offset per iteration from a
+            // wave-uniform base.  The first version computed a 64-bit address per iteration; hipcc hoisted all sixteen above the image build,
+            // spilled some, and reloaded them inside this loop with `scratch_load ; s_waitcnt vmcnt(0)` -- i.e. behind ALL earlier copy-out
+            // stores of the block: the stores went to memory one reload at a time.
+            static_assert(kTX * kTY == 128, "the index split below");
+            constexpr bool kWide = kTX >= 32;
+            const int t5 = tid >> 3, q = tid & 7;
+            const int x_lane = kWide ? t5 : t5 % kTX, y_lane = kWide ? 0 : t5 / kTX;
+            const bool cok = cb * 4 + n * 2 + (q >> 2) < nco;
+            unsigned char* ob = outb + ((size_t)tile * nco + cb * 4 + n * 2) * plane * 64;                        // wave-uniform
+            const unsigned lane_off = (unsigned)(((size_t)(q >> 2) * plane + (size_t)y_lane * a.W + x_lane) * 64 + (q & 3) * 16);   // 2 * plane * 64 < 2^32 (host check)
+            const int oyl = oy0 + y_lane, oxl = ox0 + x_lane;
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
-                const int sidx = it * 256 + tid, vox = sidx >> 3, q = sidx & 7;
-                const int oz = oz0 + vox / (kTX * kTY), oy = oy0 + (vox / kTX) % kTY, ox = ox0 + vox % kTX;
-                const int chunk = cb * 4 + n * 2 + (q >> 2);
-                if (chunk < nco && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1] && ox >= blo[2] && ox < bhi[2])
-                {
-                    float4* dstp = reinterpret_cast<float4*>(outb + srec(tile, nco, plane, chunk, ((size_t)oz * a.H + oy) * a.W + ox) + (q & 3) * 16);
-                    const float4 val = *reinterpret_cast<const float4*>(lds + sidx * 16);
+                constexpr int kDummy = 0; (void)kDummy;
+                const int c = (it & 3) * 32, zc = it >> 2;
+                const int xc = kWide ? c % kTX : 0, yc = c / kTX;
+                const int oz = oz0 + zc, oy = oyl + yc, ox = oxl + xc;
+                if (cok && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1] && ox >= blo[2] && ox < bhi[2]) {
+                    const unsigned uni = (unsigned)(((oz * a.H + oy0 + yc) * a.W + ox0 + xc) * 64);                // wave-uniform
+                    float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
+                    const float4 val = *reinterpret_cast<const float4*>(lds + (it * 256 + tid) * 16);
                     // one global_store_dwordx4 ... nt: the tensor (GBs per layer) is next read by another launch, from HBM either way (-0.9 %)
                     __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
                     __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
@@ -715,7 +740,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < a.head_ncls) {
-                        const float l = hacc[j][k] + a.head_b[k];
+                        const float l = hacc[j][k] + head_b[k];
                         float r = l;
                         if (a.head_mode != 2) {
                             const float pr = 1.0f / (1.0f + expf(-l));
@@ -883,6 +908,19 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         const int par = qok ? cg / a.Cout : 0, cchunk = qok ? (cg - par * a.Cout) >> 4 : 0;
         const unsigned poff = (unsigned)(((par >> 2) * Ho + ((par >> 1) & 1)) * Wo + (par & 1));
         const size_t inrow = (size_t)cchunk * 8 * plane * 64 + (q & 3) * 16;
+        // this lane's four column scales / shifts, loaded ONCE here: inside the loops below hipcc waits for them with vmcnt(0), which in
+        // the second half also drains the first half's sixteen copy-out stores all the way to memory
+        float scn[4], shn[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = ncol0 + n * 32 + row;
+            const bool cok = col < N;
+            const int co = cok ? col % a.Cout : 0;
+            scn[n] = cok ? a.scale[co] : 0.0f; shn[n] = cok ? a.shift[co] : 0.0f;
+        }
+        // a use on the unconditional path: the wait for the eight loads lands HERE (otherwise the wait-count pass, which merges the
+        // skipped-branch paths of the first half, puts a vmcnt(0) at their first use in the second half -- behind the stores)
+        asm volatile("" : "+v"(scn[0]), "+v"(scn[1]), "+v"(scn[2]), "+v"(scn[3]), "+v"(shn[0]), "+v"(shn[1]), "+v"(shn[2]), "+v"(shn[3]));
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
@@ -896,8 +934,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                 for (int n = 0; n < 4; ++n) {
                     const int col = ncol0 + n * 32 + row;
                     const bool cok = col < N;
-                    const int co = cok ? col % a.Cout : 0;
-                    const float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
+                    const float sc = scn[n], sh = shn[n];
                     const bool odd = row & 1;
                     const unsigned sel = odd ? 0x03020706u : 0x05040100u;
                     unsigned char* lrow = ulds + ((wn * 128 + n * 32 + row) >> 4) * 64 + ((row & 15) >> 1) * 4;
