@@ -509,7 +509,11 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             };
             for (int ch = 0; ch < nchunks; ++ch) {
                 OAI_STAMP(0);
-                __syncthreads();                                             // every wave is done reading the previous chunk
+                // every wave is done reading the previous chunk.  A bare barrier behind lgkmcnt(0): __syncthreads() would also wait (vmcnt(0)) for
+                // the weight fragments of the next tap, requested a moment ago
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
                 OAI_STAMP(1);
                 if constexpr (FIRST) { if (!OAI_DBG_BIT(a, 4)) stage_first(ch); }
                 else if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
