@@ -82,3 +82,19 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
     assert not packed, f"{len(packed)} packed fp32 VALU instructions in the library"
     assert text.count("v_mfma_f32_32x32x16_f16") > 5000 and text.count("v_mfma_f32_32x32x2_f32") > 1000
     assert text.count("global_load_lds_dwordx4") > 100
+    # (c) the copy-out of the default conv kernel (and of its ec0-fused instantiation) is a run of stores with nothing in between that waits
+    # for memory: `vmcnt` counts stores on this ISA, so a reload from scratch or a late load between them makes every store wait for all
+    # earlier ones to reach memory (profiles/r02_conv_per_layer.md section 5).  Chunk loop: no scratch traffic at all.
+    for sym in ("_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb0ELb0EEEvNS_8ConvArgsEPKh",
+                "_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb1ELb0EEEvNS_8ConvArgsEPKh"):
+        m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
+        assert m, f"{sym} not in the library"
+        body = m.group(1).split("\n")
+        mf = [i for i, ln in enumerate(body) if "v_mfma_f32_32x32x16_f16" in ln]
+        nt = [i for i, ln in enumerate(body) if "global_store_dwordx4" in ln and " nt" in ln]
+        assert len(mf) >= 600 and len(nt) >= 32
+        between = body[nt[0]:nt[-1] + 1]
+        assert not [ln for ln in between if "scratch_" in ln or "vmcnt(0)" in ln], "something waits for memory between the copy-out stores"
+        for i0, i1 in zip(mf, mf[1:]):                                   # inside a tap stream (MFMAs a few lines apart; the four ML variants lie far apart)
+            if i1 - i0 <= 60:
+                assert not [ln for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside the tap stream"
