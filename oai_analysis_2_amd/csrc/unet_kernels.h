@@ -274,7 +274,9 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
         if (co >= a.Cout) continue;
-        const float sc = a.scale[co], sh = a.shift[co];
+        float sc = a.scale[co], sh = a.shift[co];
+        asm volatile("" : "+v"(sc), "+v"(sh));      // the wait for these two loads lands HERE, once: otherwise the wait-count pass re-waits (vmcnt(0)) at the top of every
+                                                    // conditional store block below, i.e. every store waits for the previous one to reach memory (unet_sres.h, lds_dma16 notes)
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
@@ -484,7 +486,9 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
         if (co >= a.Cout) continue;
-        const float sc = a.scale[co], sh = a.shift[co];
+        float sc = a.scale[co], sh = a.shift[co];
+        asm volatile("" : "+v"(sc), "+v"(sh));      // the wait for these two loads lands HERE, once: otherwise the wait-count pass re-waits (vmcnt(0)) at the top of every
+                                                    // conditional store block below, i.e. every store waits for the previous one to reach memory (unet_sres.h, lds_dma16 notes)
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
@@ -703,7 +707,9 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm(const UpArgs a) {
         if (col >= N) continue;
         const int par = col / a.Cout, co = col - par * a.Cout;
         const int pa = par >> 2, pb = (par >> 1) & 1, pc = par & 1;
-        const float sc = a.scale[co], sh = a.shift[co];
+        float sc = a.scale[co], sh = a.shift[co];
+        asm volatile("" : "+v"(sc), "+v"(sh));      // the wait for these two loads lands HERE, once: otherwise the wait-count pass re-waits (vmcnt(0)) at the top of every
+                                                    // conditional store block below, i.e. every store waits for the previous one to reach memory (unet_sres.h, lds_dma16 notes)
         float* obase = a.out + (size_t)tile * 8 * plane * a.Cout + co;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
