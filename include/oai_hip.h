@@ -159,14 +159,36 @@ void oai_unet_destroy(oai_unet* h);
 #define OAI_PREC_FP16X3 3 /* 2 fp16 terms (22 mantissa bits), 3 fp16 MFMA passes: fp32-grade results at the BF16X3 rate; needs
                              activations below 65504 in magnitude (weights are range-scaled per output channel, exactly) */
 int oai_unet_set_precision(oai_unet* h, int mode);
-/* OAI_PREC_FP16X3 only: *out = 1 if, since the last reset, some activation was outside fp16's range (the results of
- * that run are then invalid: rerun it with OAI_PREC_F32 or OAI_PREC_BF16X6).  The read (and the reset) are ordered on
- * `stream` -- pass the stream the segment calls were queued on -- and the call blocks until that stream has drained. */
+/* OAI_PREC_FP16X3 only: *out = the range flag of the work queued since the last reset; non-zero means the results of that
+ * run are invalid and it must be repeated with OAI_PREC_F32 (what Segmenter3DInPatchClassWise / VolumePipeline do):
+ *   bit 0  an activation was beyond fp16's range (|x| * 2^e > 65504);
+ *   bit 1  some layer's largest stored activation was below 8.0 (and not zero): its low fp16 terms are subnormal, the
+ *          arithmetic is no longer fp32 grade.  Either the handle was never calibrated or this input is > 128 x quieter
+ *          than the calibration input (oai_unet_calibrate_step).
+ * A network replaces nothing in the reference here: segmenter.py:52-62 loads an arbitrary checkpoint whose per-layer
+ * activation scale is free, and networks.py:109-149 runs it in fp32, which has no such window.
+ * The read (and the reset) are ordered on `stream` -- pass the stream the segment calls were queued on -- and the call
+ * blocks until that stream has drained. */
 int oai_unet_range_flag(oai_unet* h, int reset, int* out, void* stream);
-/* Asynchronous form for pipelined callers (cohort.py): copies the flag word to dst_dev[0] and clears it, both queued on
- * `stream` behind the segment calls of ONE volume, so the flag is attributed to that volume; the caller reads dst_dev
- * with its own D2H copy of the results.  No synchronisation. */
+/* Asynchronous form for pipelined callers (cohort.py): evaluates the flag word into dst_dev[0] and clears flag and census,
+ * queued on `stream` behind the segment calls of ONE volume, so the flag is attributed to that volume; the caller reads
+ * dst_dev with its own D2H copy of the results.  No synchronisation. */
 int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream);
+/* Per-layer activation exponents of OAI_PREC_FP16X3.  Layer k (order of OAI_UNET_NUM_LAYERS) stores its output as
+ * x * 2^e[k] in fp16 term pairs; powers of two fold exactly into the epilogue affine of the producer, the epilogue scale of
+ * the consumer and -- for the skip inputs of dc8 / dc5 / dc2 -- the weight panel, so results change only where fp16's
+ * exponent range had been costing bits.  e[17] (dc0: logits) is always 0.
+ *   oai_unet_census          max |stored activation| per layer since the last reset (0 = nothing stored); blocks on `stream`.
+ *   oai_unet_calibrate_step  call after one oai_segment_tiles / oai_unet_forward_tiles pass over representative input:
+ *                            moves every layer whose maximum is outside [2^9, 2^12) to [2^10, 2^11), resets census and flag,
+ *                            *more = 1 if anything moved (run another pass and call again; a layer downstream of an overflow
+ *                            is only right after its inputs are), 0 = calibrated.  Two passes for a healthy network.
+ *   oai_unet_set_act_exponents / get  explicit form (reproducible runs, all ranks of a tile-sharded volume).  Set waits for
+ *                            the device (hipDeviceSynchronize) and rewrites the handle's epilogue arrays in place. */
+int oai_unet_census(oai_unet* h, float max_out[OAI_UNET_NUM_LAYERS], int reset, void* stream);
+int oai_unet_calibrate_step(oai_unet* h, void* stream, int* more);
+int oai_unet_get_act_exponents(const oai_unet* h, int e_out[OAI_UNET_NUM_LAYERS], int* calibrated);
+int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
 /* Result-preserving tuning options of the OAI_PREC_FP16X3 path, by name (the library does not read the environment):
  *   "sres" 0|1 (1)      activations resident as fp16 term pairs (unet_sres.h) / fp32-resident split kernels
  *   "sres_mrep" 2|4 (4) z slices per workgroup of the split-resident conv kernel

@@ -23,8 +23,16 @@ struct Layer {
     int c0 = 0, c1 = 0;                 // concat split of cin (c1 = skip channels)
     float4* panel = nullptr;            // MFMA weight panel (kinds 0,1,2 except ec0)
     float4* panel_bf[3] = {nullptr, nullptr, nullptr};   // split panels of the k3 layers: bf16 x2 terms, bf16 x3 terms, fp16 x2 terms
-    float* scale_f16 = nullptr;         // epilogue scale with the fp16 panel's per-cout power-of-two weight scaling undone
+    // fp16x3 epilogue affine (refresh_fp16_affine): scale / ws * 2^(e_out - e_in0), shift * 2^e_out with ws = the fp16 panel's per-cout
+    // power-of-two weight scale and e = the activation exponents of the layer's output / first input tensor (oai_unet::act_exp)
+    float* scale_f16 = nullptr;
+    float* shift_f16 = nullptr;
+    float* plain_f16 = nullptr;         // dc0 in fp16x3: head weights * 2^-e(dc1)
+    std::vector<float> ws;              // per-cout weight scale of the fp16 panel (exact powers of two)
+    int rel1 = 0;                       // exponent folded into the source-1 (skip) weights of the current fp16 panel: e(src0) - e(src1)
+    size_t panel_f16_floats = 0;
     std::vector<float> wk_host;         // canonical [27][cin][cout] weights of the k3 layers (for re-packing)
+    std::vector<float> scale_host, shift_host, plain_host;
     float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
     float* scale = nullptr;
     float* shift = nullptr;
@@ -37,6 +45,15 @@ struct oai_unet {
     int variant = 0;                    // 0: MREP4/KC8, 1: MREP2/KC16
     int precision = OAI_PREC_F32;
     int* range_flag = nullptr;          // device word set by the split-fp16 kernels when an activation exceeds fp16's range
+    unsigned* census = nullptr;         // [18][16] float bits: max |stored activation| per layer since the last reset (census_note)
+    int* eval_out = nullptr;            // device scratch of oai_unet_range_flag
+    // Per-tensor activation exponents of the fp16x3 path: layer k stores x * 2^act_exp[k].  fp16's low split term needs |x| >= 2^-3 to be
+    // normal; below that the pair (h0, h1) has an ABSOLUTE error floor of 2^-25, so a tensor whose values sit near 2^-10 would carry
+    // 1e-5 relative error.  Calibration (oai_unet_calibrate_step) puts every layer's maximum in [2^10, 2^11): 5 bits of
+    // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
+    int act_exp[18] = {0};
+    bool calibrated = false;
+    int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
     int xcd_group = 32;                 // logical blocks per XCD deal (option "xcd_group"; 0 = launch order)
     bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (option "sres_ring")
@@ -158,8 +175,10 @@ static inline float f16_to_f32(uint16_t h) {
 // Split-bf16 panel of conv3_igemm_bf16s: [cb][chunk of 16][tap][term][nr][lane] x 8 bf16, where lane (half h, column j)
 // holds channels 8h..8h+7 of the chunk for cout cb*64+nr*32+j.  Terms: w = t0 + t1 (+ t2), each the RNE bf16 of the rest.
 // fp16: `wscale[co]` (an exact power of two) multiplies every weight of output channel co before the split.
+// `src1_factor` (an exact power of two) multiplies the weights of the source-1 (skip) channels: the two sources of a concat layer are stored
+// with different activation exponents and the panel carries their ratio.
 static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int C0, int C1, int Cout, int NS,
-                                              bool fp16 = false, const std::vector<float>* wscale = nullptr) {
+                                              bool fp16 = false, const std::vector<float>* wscale = nullptr, float src1_factor = 1.0f) {
     const int Cin = C0 + C1, KC = 16;
     const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
     const size_t units = ((size_t)ncb * (nch0 + nch1) * 27 + 1) * NS * 2 * 64;      // 16-byte units, +1 tap of prefetch slack
@@ -178,7 +197,7 @@ static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int 
                                 const int cl = cl0 + 8 * (lane >> 5) + j;
                                 const int co = cb * 64 + nr * 32 + (lane & 31);
                                 if (cl < Csrc && co < Cout) {
-                                    float r = wk[((size_t)t * Cin + cofs + cl) * Cout + co] * (wscale ? (*wscale)[co] : 1.0f);
+                                    float r = wk[((size_t)t * Cin + cofs + cl) * Cout + co] * (wscale ? (*wscale)[co] : 1.0f) * (first ? 1.0f : src1_factor);
                                     uint16_t b = 0;
                                     for (int kk = 0; kk <= k; ++kk) {
                                         if (fp16) { b = f32_to_f16_rne(r); r -= f16_to_f32(b); }
@@ -246,6 +265,75 @@ static int upload(oai_unet* h, const std::vector<float>& v, T** dst) {
     OAI_CHECK_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     *dst = reinterpret_cast<T*>(d);
     return OAI_OK;
+}
+
+// (re)fill a device array that already exists (same size) or create it
+template <typename T>
+static int upload_into(oai_unet* h, const std::vector<float>& v, T** dst) {
+    if (!*dst) return upload(h, v, dst);
+    OAI_CHECK_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return OAI_OK;
+}
+
+// tensors a layer reads: its first source is the previous layer of the schedule (a pooled tensor keeps its producer's exponent);
+// dc8 / dc5 / dc2 also read the skips ec5 / ec3 / ec1
+static inline int layer_src0(int k) { return k - 1; }
+static inline int layer_src1(int k) { return k == DC8 ? EC5 : k == DC5 ? EC3 : k == DC2 ? EC1 : -1; }
+
+// The fp16 panel of layer k (k3 conv or k2s2 up-conv) for the current activation exponents.  Every output channel's weights are scaled
+// by the power of two that puts max|w| in [2^7, 2^8) -- exact, undone by the epilogue scale -- so that the low split term of all
+// weights down to 2^-11 of the largest stays in fp16's normal range.
+static int pack_fp16_layer(oai_unet* h, int k) {
+    Layer& L = h->L[k];
+    const int s1 = layer_src1(k);
+    const int rel1 = s1 >= 0 ? h->act_exp[layer_src0(k)] - h->act_exp[s1] : 0;
+    const float f1 = ldexpf(1.0f, rel1);
+    L.ws.assign(L.cout, 1.0f);
+    std::vector<float> panel;
+    if (L.kind == 2) {
+        for (int co = 0; co < L.cout; ++co) {
+            float amax = 0.0f;
+            for (int ci = 0; ci < L.cin; ++ci)
+                for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(L.wk_host[((size_t)ci * L.cout + co) * 8 + q]));
+            if (amax > 0.0f && std::isfinite(amax)) { int e; frexpf(amax, &e); L.ws[co] = ldexpf(1.0f, 8 - e); }   // amax = m 2^e, m in [0.5,1)
+        }
+        panel = pack_up_panel_f16(L.wk_host.data(), L.cin, L.cout, L.ws);
+    } else {
+        const int Cin = L.c0 + L.c1;
+        const size_t per = L.wk_host.size() / L.cout;                 // index i = tap * Cin + ci
+        for (int co = 0; co < L.cout; ++co) {
+            float amax = 0.0f;
+            for (size_t i = 0; i < per; ++i)
+                amax = fmaxf(amax, fabsf(L.wk_host[i * L.cout + co]) * ((int)(i % Cin) >= L.c0 ? f1 : 1.0f));
+            if (amax > 0.0f && std::isfinite(amax)) { int e; frexpf(amax, &e); L.ws[co] = ldexpf(1.0f, 8 - e); }
+        }
+        panel = pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, 2, true, &L.ws, f1);
+    }
+    if (L.panel_bf[2] && panel.size() != L.panel_f16_floats) return set_error(OAI_ERR_ARG, "fp16 panel of layer %d changed size", k);
+    L.panel_f16_floats = panel.size();
+    L.rel1 = rel1;
+    return upload_into(h, panel, &L.panel_bf[2]);
+}
+
+// The fp16x3 epilogue arrays of every layer for the current activation exponents (see Layer::scale_f16).  ec0 reads the raw volume
+// (exponent 0) and has no panel; dc0 reads dc1's records and produces logits (exponent 0): its weights carry 2^-e(dc1).
+static int refresh_fp16_affine(oai_unet* h) {
+    for (int k = 0; k < 17; ++k) {
+        Layer& L = h->L[k];
+        const int e_out = h->act_exp[k], e_in = k == EC0 ? 0 : h->act_exp[layer_src0(k)];
+        std::vector<float> sc(L.cout), sh(L.cout);
+        for (int co = 0; co < L.cout; ++co) {
+            const float ws = L.ws.empty() ? 1.0f : L.ws[co];
+            sc[co] = ldexpf(L.scale_host[co] / ws, e_out - e_in);
+            sh[co] = ldexpf(L.shift_host[co], e_out);
+        }
+        if (int rc = upload_into(h, sc, &L.scale_f16)) return rc;
+        if (int rc = upload_into(h, sh, &L.shift_f16)) return rc;
+    }
+    Layer& H = h->L[DC0];
+    std::vector<float> w(H.plain_host.size());
+    for (size_t i = 0; i < w.size(); ++i) w[i] = ldexpf(H.plain_host[i], -h->act_exp[DC1]);
+    return upload_into(h, w, &H.plain_f16);
 }
 
 struct Box { int lo[3], hi[3]; };
@@ -383,7 +471,8 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     ConvArgs a;
     if (head) a = *head;                   // the fused dc0 fields (see ConvArgs); everything else is set below
     if (first) {                           // ec0 fused into this layer's staging (first_fusable)
-        a.first_w = h->L[EC0].plain; a.first_scale = h->L[EC0].scale; a.first_shift = h->L[EC0].shift; a.first_src = *first;
+        a.first_w = h->L[EC0].plain; a.first_scale = h->L[EC0].scale_f16; a.first_shift = h->L[EC0].shift_f16; a.first_src = *first;   // (sres => fp16x3)
+        a.first_census = h->opt_census ? h->census + 16 * EC0 : nullptr;
     }
     a.boxes = boxes;
     a.pool_out = pool_out;
@@ -394,7 +483,9 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     { static const int only = diag_env("OAI_STAMP_LAYER", -1); if (only >= 0 && &L != &h->L[only]) a.stamps = nullptr; }   // one layer's budget (EC1 = 1 ...)
 #endif
     a.src0 = s0; a.src1 = s1; a.C0 = L.c0; a.C1 = s1 ? L.c1 : 0;
-    a.out = out; a.Cout = L.cout; a.scale = h->precision == OAI_PREC_FP16X3 ? L.scale_f16 : L.scale; a.shift = L.shift;
+    const bool f16 = h->precision == OAI_PREC_FP16X3;
+    a.out = out; a.Cout = L.cout; a.scale = f16 ? L.scale_f16 : L.scale; a.shift = f16 ? L.shift_f16 : L.shift;
+    a.census = h->sres && h->opt_census ? h->census + 16 * (int)(&L - h->L) : nullptr;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : h->precision == OAI_PREC_BF16X6 ? 1 : 2];
     a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
     a.ncb = (L.cout + 63) / 64;
@@ -438,9 +529,11 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     { static const int only = diag_env("OAI_STAMP_LAYER", -1); if (only >= 0 && &L != &h->L[only]) a.stamps = nullptr; }   // DC9 = 8, DC6 = 11, DC3 = 14
 #endif
     const bool split = h->precision == OAI_PREC_FP16X3 && L.panel_bf[2];
-    a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout; a.shift = L.shift;
+    a.src = src; a.Cin = L.cin; a.out = out; a.Cout = L.cout;
     a.wpanel = split ? L.panel_bf[2] : L.panel;
     a.scale = split ? L.scale_f16 : L.scale;
+    a.shift = split ? L.shift_f16 : L.shift;
+    a.census = h->sres && h->opt_census ? h->census + 16 * (int)(&L - h->L) : nullptr;
     a.D = in_dims[0]; a.H = in_dims[1]; a.W = in_dims[2];
     for (int i = 0; i < 3; ++i) { a.lo[i] = out_need.lo[i] / 2; a.hi[i] = (out_need.hi[i] + 1) / 2; }
     const int nvox = (a.hi[0] - a.lo[0]) * (a.hi[1] - a.lo[1]) * (a.hi[2] - a.lo[2]);
@@ -508,12 +601,16 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
         dim3 grid(cdiv(v0 / 2, 256), n);
         const int c = L[EC0].cout;
         unsigned char* e0s = reinterpret_cast<unsigned char*>(buf[B_E0]);
-        if (h->sres && c == 32) conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, e0s, 1, h->range_flag);
-        else if (h->sres && c == 16) conv3_first_sres_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, e0s, 1, h->range_flag);
-        else if (h->sres && c == 8) conv3_first_sres_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, e0s, 1, h->range_flag);
-        else if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
-        else if (c == 16) conv3_first_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
-        else if (c == 8) conv3_first_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale, L[EC0].shift, buf[B_E0], 1);
+        const bool f16 = h->precision == OAI_PREC_FP16X3;
+        const float* sc0 = f16 ? L[EC0].scale_f16 : L[EC0].scale;
+        const float* sh0 = f16 ? L[EC0].shift_f16 : L[EC0].shift;
+        unsigned* cen0 = h->opt_census ? h->census + 16 * EC0 : nullptr;
+        if (h->sres && c == 32) conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0);
+        else if (h->sres && c == 16) conv3_first_sres_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0);
+        else if (h->sres && c == 8) conv3_first_sres_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0);
+        else if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
+        else if (c == 16) conv3_first_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
+        else if (c == 8) conv3_first_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
         else return set_error(OAI_ERR_ARG, "ec0 cout %d unsupported (8, 16 or 32)", c);
         OAI_CHECK_LAUNCH();
     }
@@ -558,7 +655,8 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
                            need[DC1].lo[0] <= need[DC0].lo[0] && need[DC1].hi[0] >= need[DC0].hi[0];
     if (fuse_head) {
         ConvArgs ha;
-        ha.head_w = L[DC0].plain; ha.head_b = L[DC0].shift; ha.head_boxes = tb(DC0); ha.head_out = blocks_out;
+        ha.head_w = L[DC0].plain_f16; ha.head_b = L[DC0].shift;       // (fuse_head => sres => fp16x3: head weights carry 2^-e(dc1))
+        ha.head_boxes = tb(DC0); ha.head_out = blocks_out;
         ha.head_ncls = h->n_classes; ha.head_mode = out_mode;
         ha.head_k[0] = kz; ha.head_k[1] = ky; ha.head_k[2] = kx; ha.head_e[0] = ez; ha.head_e[1] = ey; ha.head_e[2] = ex;
         RUN(launch_conv3(h, L[DC1], buf[B_D2], nullptr, buf[B_D1], d[0], need[DC0], n, st, tb(DC0), nullptr, &ha));
@@ -568,15 +666,16 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
 #undef RUN
     {
         const Box& k = need[DC0];
+        const float* hw = h->precision == OAI_PREC_FP16X3 ? L[DC0].plain_f16 : L[DC0].plain;
         const int bz = k.hi[0] - k.lo[0], by = k.hi[1] - k.lo[1], bx = k.hi[2] - k.lo[2];
         dim3 grid(cdiv((size_t)bz * by * bx, 256), n);
         if (h->sres)
             head_sres_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const unsigned char*>(buf[B_D1]), L[DC0].cin, d[0][0], d[0][1], d[0][2],
-                                                   k.lo[0], k.lo[1], k.lo[2], bz, by, bx, kz, ky, kx, ez, ey, ex, L[DC0].plain,
+                                                   k.lo[0], k.lo[1], k.lo[2], bz, by, bx, kz, ky, kx, ez, ey, ex, hw,
                                                    L[DC0].shift, h->n_classes, out_mode, blocks_out, tb(DC0));
         else
         head_kernel<<<grid, 256, 0, st>>>(buf[B_D1], L[DC0].cin, d[0][0], d[0][1], d[0][2], k.lo[0], k.lo[1], k.lo[2],
-                                          bz, by, bx, kz, ky, kx, ez, ey, ex, L[DC0].plain, L[DC0].shift, h->n_classes,
+                                          bz, by, bx, kz, ky, kx, ez, ey, ex, hw, L[DC0].shift, h->n_classes,
                                           out_mode, blocks_out, tb(DC0));
         OAI_CHECK_LAUNCH();
     }
@@ -589,9 +688,26 @@ static double layer_flops(const oai_unet* h, int k, const Box& b) {
     return 2.0 * vox * taps * h->L[k].cin * h->L[k].cout;
 }
 
-__global__ void flag_snapshot_kernel(int* __restrict__ flag, int* __restrict__ dst) {
-    dst[0] = flag[0];
-    flag[0] = 0;
+// Lower edge of the calibrated range: a layer whose largest stored activation is below kLowRange (and not zero) is at least 128 x smaller
+// than at calibration time (or was never calibrated): its low split terms are subnormal and the result is no longer fp32 grade.
+constexpr float kLowRange = 8.0f;
+constexpr int kTargetExp = 10;            // calibration puts a layer's maximum in [2^10, 2^11)
+
+// dst[0] = range flag of the work queued so far: bit 0 = an activation beyond fp16's range (set by the kernels), bit 1 = a layer's
+// maximum below kLowRange (from the census).  One wave; `reset` clears the flag and the census for the next volume.
+__global__ void range_eval_kernel(int* __restrict__ flag, unsigned* __restrict__ census, int* __restrict__ dst, int reset, float low) {
+    const int t = threadIdx.x;
+    unsigned m = 0;
+    if (t < 18)
+        for (int i = 0; i < 16; ++i) m = max(m, census[t * 16 + i]);
+    const bool lowhit = t < 17 && m != 0 && __uint_as_float(m) < low;
+    const unsigned long long any = __ballot(lowhit);
+    if (t == 0) {
+        dst[0] = flag[0] | (any ? 2 : 0);
+        if (reset) flag[0] = 0;
+    }
+    if (reset && t < 18)
+        for (int i = 0; i < 16; ++i) census[t * 16 + i] = 0;
 }
 
 }  // namespace oai
@@ -634,6 +750,12 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
         h->allocs.push_back(z);
         h->zero_rec = reinterpret_cast<unsigned char*>(z);
         (void)hipMemset(z, 0, 256);
+        void* c = nullptr;
+        if (hipMalloc(&c, 18 * 16 * sizeof(unsigned) + 256) != hipSuccess) { delete h; return set_error(OAI_ERR_HIP, "oai_unet_create: hipMalloc failed"); }
+        h->allocs.push_back(c);
+        h->census = reinterpret_cast<unsigned*>(c);
+        h->eval_out = reinterpret_cast<int*>(reinterpret_cast<char*>(c) + 18 * 16 * sizeof(unsigned));
+        (void)hipMemset(c, 0, 18 * 16 * sizeof(unsigned) + 256);
     }
     h->variant = diag_env("OAI_CONV_VARIANT", 0);
     if (h->variant < 0 || h->variant > 2) h->variant = 0;
@@ -657,6 +779,7 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
                 sh[c] = (b - p.bn_mean_host[c]) * s + p.bn_beta_host[c];
             } else sh[c] = b;
         }
+        L.scale_host = sc; L.shift_host = sh;
         if ((rc = upload(h, sc, &L.scale))) break;
         if ((rc = upload(h, sh, &L.shift))) break;
         if (k == EC0) {
@@ -670,6 +793,7 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
             rc = upload(h, pack_up_panel(p), &L.panel);
         } else {
             std::vector<float> w(p.weight_host, p.weight_host + (size_t)p.cout * p.cin);
+            L.plain_host = w;
             rc = upload(h, w, &L.plain);
         }
     }
@@ -686,40 +810,16 @@ int oai_unet_set_precision(oai_unet* h, int mode) {
         const int slot = mode == OAI_PREC_BF16X3 ? 0 : mode == OAI_PREC_BF16X6 ? 1 : 2, NS = slot == 1 ? 3 : 2;
         for (int k = 1; k < 17; ++k) {
             Layer& L = h->L[k];
-            if (L.kind == 2 && slot == 2 && !L.panel_bf[2]) {      // k2s2 up-convs: split-fp16 only
-                std::vector<float> ws(L.cout, 1.0f), sc(L.cout), host_scale(L.cout);
-                for (int co = 0; co < L.cout; ++co) {
-                    float amax = 0.0f;
-                    for (int ci = 0; ci < L.cin; ++ci)
-                        for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(L.wk_host[((size_t)ci * L.cout + co) * 8 + q]));
-                    if (amax > 0.0f && std::isfinite(amax)) { int e; frexpf(amax, &e); ws[co] = ldexpf(1.0f, -e); }
-                }
-                OAI_CHECK_HIP(hipMemcpy(host_scale.data(), L.scale, L.cout * sizeof(float), hipMemcpyDeviceToHost));
-                for (int co = 0; co < L.cout; ++co) sc[co] = host_scale[co] / ws[co];
-                if (int rc = upload(h, sc, &L.scale_f16)) return rc;
-                if (int rc = upload(h, pack_up_panel_f16(L.wk_host.data(), L.cin, L.cout, ws), &L.panel_bf[2])) return rc;
+            if (slot == 2) {                                           // fp16x3: k3 convs and k2s2 up-convs (pack_fp16_layer)
+                if (!L.panel_bf[2])
+                    if (int rc = pack_fp16_layer(h, k)) return rc;
                 continue;
             }
             if ((L.kind != 0 && L.kind != 1) || L.panel_bf[slot]) continue;
-            if (slot < 2) {
-                if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS), &L.panel_bf[slot])) return rc;
-                continue;
-            }
-            // fp16: scale each output channel's weights by the power of two that puts max|w| in [0.5, 1) -- exact, and
-            // undone exactly by the epilogue scale -- so that the low split term stays in fp16's normal range
-            std::vector<float> ws(L.cout, 1.0f), sc(L.cout);
-            const size_t per = L.wk_host.size() / L.cout;
-            for (int co = 0; co < L.cout; ++co) {
-                float amax = 0.0f;
-                for (size_t i = 0; i < per; ++i) amax = fmaxf(amax, fabsf(L.wk_host[i * L.cout + co]));
-                if (amax > 0.0f && std::isfinite(amax)) { int e; frexpf(amax, &e); ws[co] = ldexpf(1.0f, -e); }   // amax = m 2^e, m in [0.5,1)
-            }
-            std::vector<float> host_scale(L.cout);
-            OAI_CHECK_HIP(hipMemcpy(host_scale.data(), L.scale, L.cout * sizeof(float), hipMemcpyDeviceToHost));
-            for (int co = 0; co < L.cout; ++co) sc[co] = host_scale[co] / ws[co];
-            if (int rc = upload(h, sc, &L.scale_f16)) return rc;
-            if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS, true, &ws), &L.panel_bf[slot])) return rc;
+            if (int rc = upload(h, pack_conv3_panel_bf(L.wk_host, L.c0, L.c1, L.cout, NS), &L.panel_bf[slot])) return rc;
         }
+        if (slot == 2 && !h->L[EC0].scale_f16)
+            if (int rc = refresh_fp16_affine(h)) return rc;
     }
     h->precision = mode;
     h->sres = mode == OAI_PREC_FP16X3 && h->opt_sres;
@@ -745,6 +845,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "b_lds")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: b_lds must be 0 or 1");
         h->b_lds = value;
+    } else if (!strcmp(name, "census")) {
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: census must be 0 or 1");
+        h->opt_census = value;
     } else if (!strcmp(name, "fuse_first")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: fuse_first must be 0 or 1");
         h->fuse_first = value;
@@ -760,20 +863,85 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
 int oai_unet_range_flag(oai_unet* h, int reset, int* out, void* stream) {
     OAI_CHECK_ARG(h && out, "oai_unet_range_flag: null pointer");
     // ordered on the caller's stream (the one the segment calls were queued on): torch's side streams are non-blocking, so
-    // the null stream would not wait for them and an overflow could be read -- and reset -- before the kernels that set it ran
+    // the null stream would not wait for them and a flag could be read -- and reset -- before the kernels that set it ran
     hipStream_t st = (hipStream_t)stream;
-    OAI_CHECK_HIP(hipMemcpyAsync(out, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    range_eval_kernel<<<1, 64, 0, st>>>(h->range_flag, h->census, h->eval_out, reset, kLowRange);
+    OAI_CHECK_LAUNCH();
+    OAI_CHECK_HIP(hipMemcpyAsync(out, h->eval_out, sizeof(int), hipMemcpyDeviceToHost, st));
     OAI_CHECK_HIP(hipStreamSynchronize(st));
-    if (reset && *out) OAI_CHECK_HIP(hipMemsetAsync(h->range_flag, 0, sizeof(int), st));
     return OAI_OK;
 }
 
 int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream) {
     OAI_CHECK_ARG(h && dst_dev, "oai_unet_range_flag_snapshot: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    flag_snapshot_kernel<<<1, 1, 0, st>>>(h->range_flag, dst_dev);       // a kernel: stream-ordered with the conv launches around it
+    range_eval_kernel<<<1, 64, 0, st>>>(h->range_flag, h->census, dst_dev, 1, kLowRange);   // a kernel: stream-ordered with the conv launches around it
     OAI_CHECK_LAUNCH();
     return OAI_OK;
+}
+
+int oai_unet_census(oai_unet* h, float max_out[OAI_UNET_NUM_LAYERS], int reset, void* stream) {
+    OAI_CHECK_ARG(h && max_out, "oai_unet_census: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned host[18 * 16];
+    OAI_CHECK_HIP(hipMemcpyAsync(host, h->census, sizeof(host), hipMemcpyDeviceToHost, st));
+    OAI_CHECK_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 18; ++k) {
+        unsigned m = 0;
+        for (int i = 0; i < 16; ++i) m = host[k * 16 + i] > m ? host[k * 16 + i] : m;
+        memcpy(&max_out[k], &m, 4);
+    }
+    if (reset) {
+        OAI_CHECK_HIP(hipMemsetAsync(h->census, 0, sizeof(host), st));
+        OAI_CHECK_HIP(hipMemsetAsync(h->range_flag, 0, sizeof(int), st));
+    }
+    return OAI_OK;
+}
+
+int oai_unet_get_act_exponents(const oai_unet* h, int e_out[OAI_UNET_NUM_LAYERS], int* calibrated) {
+    OAI_CHECK_ARG(h && e_out, "oai_unet_get_act_exponents: null pointer");
+    for (int k = 0; k < 18; ++k) e_out[k] = h->act_exp[k];
+    if (calibrated) *calibrated = h->calibrated ? 1 : 0;
+    return OAI_OK;
+}
+
+int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]) {
+    OAI_CHECK_ARG(h && e, "oai_unet_set_act_exponents: null pointer");
+    for (int k = 0; k < 17; ++k) OAI_CHECK_ARG(e[k] >= -100 && e[k] <= 100, "oai_unet_set_act_exponents: exponent %d of layer %d outside [-100, 100]", e[k], k);
+    OAI_CHECK_ARG(e[DC0] == 0, "oai_unet_set_act_exponents: dc0 produces logits, its exponent must be 0");
+    OAI_CHECK_HIP(hipDeviceSynchronize());               // the arrays rewritten below may be in use by queued launches (rare call: once per network)
+    for (int k = 0; k < 18; ++k) h->act_exp[k] = e[k];
+    h->calibrated = true;
+    if (!h->L[EC0].scale_f16) return OAI_OK;             // fp16x3 not set up yet: oai_unet_set_precision packs with these exponents
+    for (int k : {DC8, DC5, DC2}) {                      // concat layers: the panel carries 2^(e(src0) - e(src1)) on the skip channels
+        const int rel1 = h->act_exp[layer_src0(k)] - h->act_exp[layer_src1(k)];
+        if (rel1 != h->L[k].rel1)
+            if (int rc = pack_fp16_layer(h, k)) return rc;
+    }
+    return refresh_fp16_affine(h);
+}
+
+int oai_unet_calibrate_step(oai_unet* h, void* stream, int* more) {
+    OAI_CHECK_ARG(h && more, "oai_unet_calibrate_step: null pointer");
+    OAI_CHECK_ARG(h->precision == OAI_PREC_FP16X3, "oai_unet_calibrate_step: the activation exponents belong to OAI_PREC_FP16X3");
+    float mx[18];
+    if (int rc = oai_unet_census(h, mx, 1, stream)) return rc;
+    int e[18], changed = 0;
+    for (int k = 0; k < 18; ++k) e[k] = h->act_exp[k];
+    for (int k = 0; k < 17; ++k) {
+        if (!(mx[k] > 0.0f)) continue;                   // nothing stored (layer not run by the split-resident kernels, or all zero): keep
+        if (!std::isfinite(mx[k])) { e[k] -= 32; changed = 1; continue; }
+        int b;
+        frexpf(mx[k], &b);                               // mx = m 2^b, m in [0.5, 1): mx in [2^(b-1), 2^b)
+        if (b - 1 >= kTargetExp - 1 && b - 1 <= kTargetExp + 1) continue;       // inside [2^9, 2^12): leave it (a verify pass ends here)
+        e[k] += kTargetExp - (b - 1);
+        if (e[k] > 100) e[k] = 100;
+        if (e[k] < -100) e[k] = -100;
+        changed = 1;
+    }
+    *more = changed;
+    if (!changed) { h->calibrated = true; return OAI_OK; }
+    return oai_unet_set_act_exponents(h, e);
 }
 
 int oai_unet_profile(oai_unet* h, int enable) {

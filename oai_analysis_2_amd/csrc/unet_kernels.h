@@ -77,6 +77,9 @@ struct ConvArgs {
                                              // (tiles at the volume border need less: their kept centre is partly zeroed)
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
     int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
+    unsigned* census = nullptr;              // split-resident kernels: 16 words of this layer's max |stored activation| (float bits, atomicMax;
+                                             // see census_note).  Feeds the per-layer activation exponents and the low-range flag
+    unsigned* first_census = nullptr;        // ... of the fused ec0 (instantiation FIRST)
     int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
     unsigned long long* stamps = nullptr;    // -DOAI_DIAG builds: device array of phase cycle sums (oai_diag_stamps); never set in production
     int nblocks = 0, xcd_group = 0;          // split-resident kernel: true workgroup count and the XCD dealing granularity (see xcd_block_id)
@@ -536,6 +539,7 @@ struct UpArgs {
     int relu;
     const int* boxes;                   // optional [tile][6]: the part of the INPUT box this tile needs
     int* range_flag;                    // split-fp16: set when an input is outside fp16's range
+    unsigned* census = nullptr;         // split-resident kernel: this layer's 16 census words (see ConvArgs::census)
     const unsigned char* zero = nullptr; // split-resident kernel: 64 zero bytes, the LDS-DMA source of rows / columns that do not exist
     unsigned long long* stamps = nullptr;   // -DOAI_DIAG builds: phase cycle sums of the up-conv kernel at stamps[16..31]
     int dbg = 0;                        // diagnostic timing switches (OAI_DBG bits 64/128/256/512; results wrong when set)

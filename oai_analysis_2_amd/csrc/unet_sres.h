@@ -37,6 +37,19 @@ __device__ __forceinline__ float join2_f16(unsigned short hi, unsigned short lo)
     return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
 }
 
+// Range bookkeeping of a workgroup's stored activations (vmax = this lane's max |value|, >= 0): one wave reduction, then lane 0 sets the
+// overflow flag (fp16 cannot hold |x| > 65504: report, never silently inf) and folds the wave's maximum into the layer's census -- 16 words
+// per layer, picked by block id so that the ~10^5 waves of a launch do not queue on one L2 atomic unit.  The census is what
+// oai_unet_calibrate_step turns into per-layer power-of-two activation exponents, and what the range flag's LOW bit is derived from.
+__device__ __forceinline__ void census_note(unsigned* census, int* range_flag, float vmax) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+        if (!(vmax <= 65504.0f)) atomicOr(range_flag, 1);
+        if (census && vmax > 0.0f) atomicMax(census + (blockIdx.x & 15), __float_as_uint(vmax));
+    }
+}
+
 // byte offset of the 64-byte record (tile, chunk, voxel) of a format-S tensor with `nch` chunks and `plane` voxels per tile.
 // Chunk-planar: the records of x-consecutive voxels of one chunk are contiguous, so a halo row is one dense run for the LDS-DMA
 // (with the chunks interleaved per voxel every DMA instruction touched 16 lines instead of 4-5: 7 % of the segmentation).
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     };
 
     // ---- FIRST: the raw patch, then ec0 on the VALU straight into the halo box (chunk ch = ec0 channels [16 ch, 16 ch + 16))
-    int first_bad = 0;
+    float first_max = 0.0f;                       // FIRST: max of the ec0 values this thread produced (>= 0 behind the ReLU)
     if constexpr (FIRST) {
         const TileSource& s = a.first_src;
         if (tid < PZ + PY + PX) {
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 float x = e[v][c] * fsc[c] + fsh[c];
                 x = fmaxf(x, 0.0f);
                 if (!inside[v]) x = 0.0f;                                                     // ec1's own zero padding at the tile border
-                first_bad |= !(fabsf(x) <= 65504.0f);
+                first_max = fmaxf(first_max, x);
                 unsigned l;
                 hi[c >> 3][c & 7] = (unsigned short)split2_f16(x, l);
                 lo[c >> 3][c & 7] = (unsigned short)l;
@@ -755,7 +768,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             }
         }
     }
-    if (!(vmax <= 65504.0f) || first_bad) atomicOr(a.range_flag, 1);           // fp16 cannot hold it: report, never silently inf
+    if constexpr (FIRST) census_note(a.first_census, a.range_flag, first_max);
+    census_note(a.census, a.range_flag, vmax);
 #ifdef OAI_DIAG
     OAI_STAMP(6);
     OAI_STAMPB(6);
@@ -972,7 +986,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             }
             OAI_USTAMP(4);
         }
-        if (!(vmax <= 65504.0f)) atomicOr(a.range_flag, 1);
+        census_note(a.census, a.range_flag, vmax);
 #ifdef OAI_DIAG
         OAI_USTAMP(4);
         if (a.stamps && lane == 0) {
@@ -983,7 +997,27 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         return;
     }
     // ---- narrow test networks (Cout not a multiple of 16): dword stores straight from the accumulators
-    if (!active) return;
+    if (!active) return;                                                  // (wave-uniform)
+    {   // range census in a pass of its own over the accumulators (tracked inside the store loop below it cost 58 VGPRs and 168 B of scratch)
+        float nmax = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = ncol0 + n * 32 + row;
+            const bool cok = col < N;
+            const int co = cok ? col % a.Cout : 0;
+            const float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned e = vtab[wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                    float val = acc[m][n][r] * sc + sh;
+                    if (a.relu) val = fmaxf(val, 0.0f);
+                    if (cok && e != ~0u) nmax = fmaxf(nmax, fabsf(val));
+                }
+        }
+        census_note(a.census, a.range_flag, nmax);
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int col = ncol0 + n * 32 + row;
@@ -1008,7 +1042,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 template <int COUT>
 __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource s, const float* __restrict__ wk, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, unsigned char* __restrict__ out, int relu,
-                                                               int* __restrict__ range_flag) {
+                                                               int* __restrict__ range_flag, unsigned* __restrict__ census) {
     __shared__ __attribute__((aligned(16))) float wl[27 * COUT];
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) wl[i] = wk[i];
     __syncthreads();
@@ -1075,6 +1109,7 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
     }
     constexpr int NCH = (COUT + 15) / 16;
     const size_t v = ((size_t)z * s.th + y) * s.tw + x;
+    float rmax = 0.0f;
 #pragma unroll
     for (int vv = 0; vv < 2; ++vv) {
 #pragma unroll
@@ -1086,7 +1121,7 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
                 const int c = ch * 16 + j;
                 float r = 0.0f;
                 if (c < COUT) { r = acc[vv][c < COUT ? c : 0] * scale[c < COUT ? c : 0] + shift[c < COUT ? c : 0]; if (relu) r = fmaxf(r, 0.0f); }
-                if (!(fabsf(r) <= 65504.0f)) atomicOr(range_flag, 1);
+                rmax = fmaxf(rmax, fabsf(r));
                 unsigned l;
                 hi[j >> 3][j & 7] = (unsigned short)split2_f16(r, l);
                 lo[j >> 3][j & 7] = (unsigned short)l;
@@ -1097,6 +1132,7 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
             *reinterpret_cast<u16x8*>(o + 48) = lo[1];
         }
     }
+    census_note(census, range_flag, rmax);      // (whole blocks leave at the top: plane / 2 is a multiple of 256)
 }
 
 // ---- MaxPool3d(2) on format S (fallback when the pooling cannot ride in the conv epilogue) -----------------------------------

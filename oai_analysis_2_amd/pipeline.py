@@ -96,8 +96,9 @@ class VolumePipeline:
         return res
 
     def rerun_f32(self, vol: torch.Tensor, meta_A: Image, sharded_group="none") -> VolumeResult:
-        """The volume overflowed fp16's range: repeat it with exact fp32 MFMA arithmetic (what Segmenter3DInPatchClassWise does)."""
-        print("WARNING: activation outside fp16 range, repeating the volume in fp32")
+        """The volume left fp16x3's calibrated range window (range flag: overflow or a layer far quieter than at calibration): repeat
+        it with exact fp32 MFMA arithmetic (what Segmenter3DInPatchClassWise does)."""
+        print("WARNING: activations outside the fp16x3 range window, repeating the volume in fp32")
         prev = self.unet.precision
         self.unet.set_precision("f32")
         try:

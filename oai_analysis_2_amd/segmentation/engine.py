@@ -85,6 +85,10 @@ class UNetEngine:
         self._h = handle
         self._ws: Optional[torch.Tensor] = None
         self.precision = "f32"
+        # fp16x3: per-layer power-of-two activation exponents, chosen from a range census of the first input this engine sees
+        # (calibrate()).  False = leave them as they are (all zero unless set_act_exponents was called).
+        self.auto_calibrate = True
+        self._calibrated = False
         if precision != "f32":
             self.set_precision(precision)
 
@@ -126,14 +130,62 @@ class UNetEngine:
         """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds": include/oai_hip.h)."""
         _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
 
-    def range_overflow(self, reset: bool = True) -> bool:
-        """fp16x3 only: True if an activation left fp16's range since the last reset (that run must be repeated in
-        "f32" / "bf16x6").  Ordered on the current stream of this engine's device; synchronises that stream."""
+    def range_flag(self, reset: bool = True) -> int:
+        """fp16x3 only: the range flag of the work queued since the last reset -- bit 0: an activation beyond fp16's range, bit 1: a
+        layer whose largest stored activation is below the calibrated window (include/oai_hip.h).  Non-zero = repeat that run in
+        "f32".  Ordered on the current stream of this engine's device; synchronises that stream."""
         out = C.c_int(0)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_unet_range_flag(self._h, int(reset), C.byref(out), torch.cuda.current_stream().cuda_stream),
                        "oai_unet_range_flag")
-        return bool(out.value)
+        return int(out.value)
+
+    def range_overflow(self, reset: bool = True) -> bool:
+        """True if the fp16x3 results queued since the last reset must not be used (range_flag() != 0)."""
+        return self.range_flag(reset) != 0
+
+    # ---- activation exponents of fp16x3 ---------------------------------------------------------------------------------------
+    def census(self, reset: bool = False):
+        """max |stored activation| of each of the 18 layers since the last reset (0.0 = nothing stored); synchronises the stream."""
+        out = (C.c_float * 18)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_census(self._h, out, int(reset), torch.cuda.current_stream().cuda_stream), "oai_unet_census")
+        return list(out)
+
+    def act_exponents(self):
+        """(exponents of the 18 layers, calibrated?)"""
+        e, cal = (C.c_int * 18)(), C.c_int(0)
+        _lib.check(self.lib.oai_unet_get_act_exponents(self._h, e, C.byref(cal)), "oai_unet_get_act_exponents")
+        return list(e), bool(cal.value)
+
+    def set_act_exponents(self, exponents) -> None:
+        """Explicit exponents (e.g. those of another rank, or saved next to a checkpoint); marks the engine calibrated."""
+        if len(exponents) != 18:
+            raise ValueError("need one exponent per layer (18)")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_set_act_exponents(self._h, (C.c_int * 18)(*[int(v) for v in exponents])), "oai_unet_set_act_exponents")
+        self._calibrated = True
+
+    def calibrate(self, run_pass, max_passes: int = 24) -> int:
+        """Choose the activation exponents from representative input: ``run_pass()`` queues one fp16x3 pass (segment_tiles /
+        forward_tiles) on the current stream; repeated until every layer's maximum sits in the calibrated window (two passes for
+        a network whose activations fit fp16 to begin with; one more per layer that overflowed on the way).  Returns the passes."""
+        if self.precision != "fp16x3":
+            raise _lib.OaiError("activation exponents belong to precision 'fp16x3'")
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            self.census(reset=True)
+            for n in range(1, max_passes + 1):
+                run_pass()
+                more = C.c_int(0)
+                _lib.check(self.lib.oai_unet_calibrate_step(self._h, st, C.byref(more)), "oai_unet_calibrate_step")
+                if not more.value:
+                    self._calibrated = True
+                    return n
+        raise _lib.OaiError(f"fp16x3 calibration did not settle in {max_passes} passes (census {self.census()}): use precision 'f32'")
+
+    def _needs_calibration(self) -> bool:
+        return self.precision == "fp16x3" and self.auto_calibrate and not self._calibrated
 
     def range_overflow_snapshot(self, dst: torch.Tensor) -> None:
         """Queue (current stream, no sync) a copy of the fp16 range flag into the int32 device tensor ``dst[0]`` and clear it:
@@ -167,10 +219,15 @@ class UNetEngine:
         B, _, d, h, w = tiles.shape
         ws = self._workspace((d, h, w), min(B, batch or self.auto_batch((d, h, w), B)))      # the C side loops over what the workspace holds
         out = torch.empty((B, self.n_classes, d, h, w), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.oai_unet_forward_tiles(self._h, tiles.data_ptr(), out.data_ptr(), B, d, h, w,
-                                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
-                       "oai_unet_forward_tiles")
+
+        def launch():
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.oai_unet_forward_tiles(self._h, tiles.data_ptr(), out.data_ptr(), B, d, h, w,
+                                                           ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                           "oai_unet_forward_tiles")
+        if self._needs_calibration():
+            self.calibrate(launch)
+        launch()
         return out
 
     def volume_flops(self, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None, trimmed: bool = True, conv3_only: bool = False) -> float:
@@ -199,16 +256,32 @@ class UNetEngine:
             batch = self.auto_batch(tile_zyx, end - begin)
         batch = max(1, min(int(batch), max(1, end - begin)))
         self.last_batch = batch
+        if self._needs_calibration():
+            # on the WHOLE volume whatever range was asked for: every rank of a tile-sharded volume arrives at the same exponents
+            self.calibrate_volume(vol, tile_zyx, overlap_zyx, crop_zyx, batch=None if (begin, end) != (0, ntiles) else batch)
         ws = self._workspace(tile_zyx, batch)
         blocks = torch.empty((end - begin, self.n_classes, *eff), dtype=torch.float32, device=self.device)
         if end > begin:
-            with torch.cuda.device(self.device):
-                _lib.check(self.lib.oai_segment_tiles(self._h, vol.data_ptr(), D, H, W, _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
-                                                      _lib.int3(crop_zyx) if crop_zyx is not None else None,
-                                                      int(begin), int(end), int(out_mode), blocks.data_ptr(), batch,
-                                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
-                           "oai_segment_tiles")
+            self._launch_segment(vol, tile_zyx, overlap_zyx, crop_zyx, begin, end, out_mode, blocks, batch, ws)
         return blocks
+
+    def _launch_segment(self, vol, tile_zyx, overlap_zyx, crop_zyx, begin, end, out_mode, blocks, batch, ws) -> None:
+        D, H, W = vol.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_segment_tiles(self._h, vol.data_ptr(), D, H, W, _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
+                                                  _lib.int3(crop_zyx) if crop_zyx is not None else None,
+                                                  int(begin), int(end), int(out_mode), blocks.data_ptr(), batch,
+                                                  ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                       "oai_segment_tiles")
+
+    def calibrate_volume(self, vol: torch.Tensor, tile_zyx, overlap_zyx, crop_zyx=None, batch: Optional[int] = None) -> int:
+        """calibrate() on all tiles of ``vol`` (the census is a maximum: the result does not depend on batching or tile order)."""
+        vol = vol.to(self.device, torch.float32).contiguous()
+        eff, grid, ntiles = tile_grid(vol.shape, tile_zyx, overlap_zyx)
+        batch = max(1, min(int(batch or self.auto_batch(tile_zyx, ntiles)), ntiles))
+        ws = self._workspace(tile_zyx, batch)
+        blocks = torch.empty((ntiles, self.n_classes, *eff), dtype=torch.float32, device=self.device)
+        return self.calibrate(lambda: self._launch_segment(vol, tile_zyx, overlap_zyx, crop_zyx, 0, ntiles, 0, blocks, batch, ws))
 
     def stitch(self, blocks: torch.Tensor, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None) -> torch.Tensor:
         """maps[n_classes, D, H, W] (Partition.assemble, non-vote branch)."""

@@ -94,8 +94,9 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
                                    crop_zyx if min(crop_zyx) > 0 else None)
         if precision == "fp16x3" and eng.range_overflow():
-            # an activation beyond fp16's range (|x| > 65504): repeat this volume with exact fp32 MFMA arithmetic
-            print("WARNING: activation outside fp16 range, repeating the segmentation in fp32")
+            # outside the calibrated window (an activation beyond 65504, or a layer > 128 x quieter than at calibration): repeat this
+            # volume with exact fp32 MFMA arithmetic
+            print("WARNING: activations outside the fp16x3 range window, repeating the segmentation in fp32")
             eng.set_precision("f32")
             blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
                                        crop_zyx if min(crop_zyx) > 0 else None)

@@ -1,0 +1,158 @@
+"""GPU: the range window of the default fp16x3 arithmetic.
+
+A checkpoint's per-layer activation scale is free (segmenter.py:52-62 loads whatever it is given; BN=False leaves it unnormalised) and the
+reference runs in fp32, which does not care.  fp16 term pairs do: |x| > 65504 overflows, and below 2^-3 the low term goes subnormal (an
+absolute error floor of 2^-25).  Multiplying one layer's weight and bias by 2^-k and the next layer's weight by 2^k leaves the fp32 network
+BIT-IDENTICAL (powers of two commute with ReLU and with every rounding), so the reference's goldens apply unchanged to the rescaled
+networks below -- and the fp16x3 path must meet the same gates on them as on the original: calibrated per-layer power-of-two activation
+exponents (oai_unet_calibrate_step), and a flag -- never silence -- when a run leaves the calibrated window."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oai_analysis_2_amd.synth import make_unet_state_dict, make_volume
+from oracle import seg as oseg
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def rescale(sd, producer, k, consumers):
+    """producer.{weight,bias} * 2^-k; each consumer (name, cin slice or None) weight * 2^k on the channels that read the producer."""
+    sd = {n: v.clone() for n, v in sd.items()}
+    sd[f"{producer}.0.weight"] *= 2.0 ** -k
+    sd[f"{producer}.0.bias"] *= 2.0 ** -k
+    for name, sl in consumers:
+        w = sd[f"{name}.0.weight"]
+        cin_axis = 1 if name.startswith("ec") else 0            # Conv3d [cout, cin, ...]; ConvTranspose3d [cin, cout, ...]
+        idx = [slice(None)] * w.dim()
+        idx[cin_axis] = sl if sl is not None else slice(None)
+        w[tuple(idx)] *= 2.0 ** k
+    return sd
+
+
+CASES = {
+    "ec0_down10": ("ec0", 10, [("ec1", None)]),
+    "ec0_down14": ("ec0", 14, [("ec1", None)]),
+    "dc5_down10": ("dc5", 10, [("dc4", None)]),
+    "dc5_down14": ("dc5", 14, [("dc4", None)]),
+    "dc8_down12": ("dc8", 12, [("dc7", None)]),
+    # a skip tensor 2^10 quieter than the up-conv tensor it is concatenated with (dc2 reads cat(dc3: 128, ec1: 64), networks.py:141)
+    "ec1_skip_down10": ("ec1", 10, [("ec2", None), ("dc2", slice(128, 192))]),
+    # ... and louder, far beyond fp16 (activations ~2^14 x O(1)): calibration has to walk through the overflow
+    "ec3_skip_up14": ("ec3", -14, [("ec4", None), ("dc5", slice(256, 384))]),
+    "dc3_up16": ("dc3", -16, [("dc2", slice(0, 128))]),
+}
+
+
+@pytest.fixture(scope="module")
+def tile_setup(golden_dir):
+    z = np.load(os.path.join(golden_dir, "unet_fulltile.npz"))
+    vol = make_volume(int(z["volume_seed"]), (32, 128, 128))
+    sd = make_unet_state_dict(seed=int(z["weight_seed"]))
+    x = torch.from_numpy(vol)[None, None].cuda()
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    eng = UNetEngine(sd, precision="fp16x3")
+    base = eng.forward_tiles(x).cpu().numpy()[0][:, 8:24, 16:112, 16:112]
+    assert eng.range_flag() == 0
+    err0 = np.abs(base - z["logits_centre"]).max() / float(z["logits_abs_max"])
+    return dict(z=z, sd=sd, x=x, base=base, err0=err0)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_rescaled_network_meets_the_golden_gates(tile_setup, case):
+    """One full 32x128x128 tile of the reference golden (unet_fulltile.npz) through the power-of-two-rescaled network."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z, x = tile_setup["z"], tile_setup["x"]
+    sd = rescale(tile_setup["sd"], *CASES[case])
+    # exact fp32 MFMA: the rescaled network is the same function
+    e32 = UNetEngine(sd, precision="f32")
+    got32 = e32.forward_tiles(x).cpu().numpy()[0][:, 8:24, 16:112, 16:112]
+    assert np.abs(got32 - z["logits_centre"]).max() / float(z["logits_abs_max"]) < REL
+    # fp16x3, calibrated on first use
+    eng = UNetEngine(sd, precision="fp16x3")
+    got = eng.forward_tiles(x).cpu().numpy()[0][:, 8:24, 16:112, 16:112]
+    assert eng.range_flag() == 0, "a calibrated engine must be inside its window on its calibration input"
+    exps, cal = eng.act_exponents()
+    err = np.abs(got - z["logits_centre"]).max() / float(z["logits_abs_max"])
+    drift = np.abs(got - tile_setup["base"]).max() / float(z["logits_abs_max"])
+    print(f"[rescaled {case}] fp16x3 logits rel err {err:.2e} (unscaled network {tile_setup['err0']:.2e}), vs unscaled fp16x3 {drift:.2e}; exponents {exps}")
+    assert cal and err < REL
+    assert err < 2.0 * tile_setup["err0"] + 1e-6          # same grade as on the original network, not merely inside 1e-4
+    prob_ref = 1.0 / (1.0 + np.exp(-z["logits_centre"].astype(np.float64)))
+    prob = 1.0 / (1.0 + np.exp(-got.astype(np.float64)))
+    assert np.abs(prob - prob_ref).sum() * (23592960 / prob_ref[0].size) < 12.0       # test_all.py:32-33, scaled to a volume
+    # every layer that stores something sits in the calibrated window
+    eng.forward_tiles(x)
+    cen = eng.census(reset=True)
+    assert all(c == 0.0 or 2.0 ** 9 <= c < 2.0 ** 12 for c in cen[:17]), cen
+
+
+def test_uncalibrated_low_range_is_flagged_not_silent(tile_setup):
+    """Without calibration the quiet layer costs precision -- and bit 1 of the range flag says so; Segmenter / VolumePipeline repeat in fp32."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z, x = tile_setup["z"], tile_setup["x"]
+    sd = rescale(tile_setup["sd"], *CASES["ec0_down14"])
+    eng = UNetEngine(sd, precision="fp16x3")
+    eng.auto_calibrate = False
+    got = eng.forward_tiles(x).cpu().numpy()[0][:, 8:24, 16:112, 16:112]
+    flag = eng.range_flag()
+    err = np.abs(got - z["logits_centre"]).max() / float(z["logits_abs_max"])
+    print(f"[uncalibrated ec0 * 2^-14] flag {flag}, logits rel err {err:.2e} (calibrated: ~{tile_setup['err0']:.1e})")
+    assert flag & 2
+    assert err > 10 * tile_setup["err0"], "the hole this mechanism closes should be visible without it"
+    assert eng.range_flag() == 0                           # reported once, then reset
+
+
+def test_quieter_and_louder_inputs_leave_the_window_and_are_flagged(tile_setup):
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    x = tile_setup["x"]
+    # without biases the network is positively homogeneous: an input s x scales every activation by s
+    sd = {k: (torch.zeros_like(v) if k.endswith(".bias") else v) for k, v in tile_setup["sd"].items()}
+    eng = UNetEngine(sd, precision="fp16x3")
+    eng.forward_tiles(x)
+    assert eng.range_flag() == 0
+    e0, _ = eng.act_exponents()
+    eng.forward_tiles(x * 0.25)                            # inside the window: 128 x of room below, 32 x above
+    assert eng.range_flag() == 0
+    eng.forward_tiles(x * 1e-4)                            # 10^4 x quieter than the calibration input
+    assert eng.range_flag() & 2
+    eng.forward_tiles(x * 1e3)                             # beyond the 5-6 bits of headroom
+    assert eng.range_flag() & 1
+    assert eng.act_exponents()[0] == e0                    # flags do not move the calibration
+    # exponents travel: a second engine given them reproduces the first bit for bit (ranks of a sharded volume, saved calibrations)
+    eng2 = UNetEngine(sd, precision="fp16x3")
+    eng2.set_act_exponents(e0)
+    assert torch.equal(eng2.forward_tiles(x), eng.forward_tiles(x))
+
+
+def test_rescaled_network_full_volume_vs_reference_golden(golden_dir):
+    """The whole 384x384x160 volume of segment_fullsize.npz (the reference's own segment() run) through a rescaled network, default arithmetic."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    SHAPE, TILE, OVL, CROP = (160, 384, 384), (32, 128, 128), (8, 16, 16), (8, 16, 16)
+    z = np.load(os.path.join(golden_dir, "segment_fullsize.npz"))
+    sd = make_unet_state_dict(int(z["weight_seed"]))
+    sd = rescale(sd, *CASES["ec0_down10"])
+    sd = rescale(sd, *CASES["dc5_down14"])
+    eng = UNetEngine(sd, precision="fp16x3")
+    v = torch.from_numpy(make_volume(int(z["volume_seed"]), SHAPE)).cuda()
+    prob = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=0, crop_zyx=CROP), SHAPE, TILE, OVL, CROP).cpu().numpy()
+    assert eng.range_flag() == 0
+    n = prob[0].size
+    sl = tuple(slice(int(a), None, int(st)) for a, st in zip(z["start"], z["stride"]))
+    for c, key in enumerate(("fc_prob_s", "tc_prob_s")):
+        ref_s = z[key].astype(np.float64)
+        d = np.abs(prob[c][sl].astype(np.float64) - ref_s)
+        scaled = d.sum() * (n / ref_s.size)
+        print(f"[fullsize rescaled fp16x3] class {c}: sum|dp| scaled to 23.6M voxels = {scaled:.3f} (budget 12), max|dp| = {d.max():.2e}")
+        assert scaled < 12.0 and d.max() < 1e-5
+    mask = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=1, crop_zyx=CROP), SHAPE, TILE, OVL, CROP).cpu().numpy() > 0.5
+    ref_mask = np.stack([np.unpackbits(z["fc_mask_bits"])[:n], np.unpackbits(z["tc_mask_bits"])[:n]]).astype(bool).reshape(2, *SHAPE)
+    flips = np.flatnonzero((mask != ref_mask).ravel())
+    near = dict(zip(z["near_idx"].tolist(), z["near_prob"].tolist()))
+    dist_ = [abs(near.get(int(i), 0.0) - 0.5) for i in flips]
+    print(f"[fullsize rescaled fp16x3] mask flips vs the reference: {len(flips)} of {2 * n}; max |p_ref - 0.5| at a flip = {max(dist_, default=0.0):.2e}; "
+          f"exponents {eng.act_exponents()[0]}")
+    assert all(d < 1e-5 for d in dist_) and len(flips) <= 64

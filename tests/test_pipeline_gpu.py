@@ -50,6 +50,7 @@ def test_pipeline_and_cohort_repeat_an_overflowing_volume_in_fp32():
     sd = make_unet_state_dict(seed=7, width_div=2)
     big = {k: (v * 1e6 if k == "ec0.0.weight" else v) for k, v in sd.items()}
     pipe, shape = _small_pipe(big, "fp16x3")
+    pipe.unet.auto_calibrate = False          # exponents all zero: a volume outside the window (calibrated, this checkpoint is simply fine)
     ref_pipe, _ = _small_pipe(big, "f32")
     vols = [make_volume(20 + i, shape) for i in range(3)]
     meta = Image(vols[0], [0.36, 0.37, 0.7], [1.0, 2.0, 3.0])
@@ -57,7 +58,7 @@ def test_pipeline_and_cohort_repeat_an_overflowing_volume_in_fp32():
     ref = ref_pipe.run(v, meta)
     assert ref.overflow is None and not ref.repeated_f32
     raw = pipe.run(v, meta, check=False)
-    assert int(raw.overflow.item()) == 1
+    assert int(raw.overflow.item()) & 1
     res = pipe.run(v, meta)
     assert res.repeated_f32 and pipe.unet.precision == "fp16x3"
     assert torch.equal(res.fc, ref.fc) and torch.equal(res.tc_atlas, ref.tc_atlas)

@@ -204,11 +204,19 @@ def test_fp16x3_reports_activations_outside_fp16_range():
     assert not eng.range_overflow()
     big = {k: (v * 1e6 if k == "ec0.0.weight" else v) for k, v in sd.items()}       # e0 ~ 1e6 > 65504
     eng2 = UNetEngine(big, precision="fp16x3")
+    eng2.auto_calibrate = False                                                         # exponents all zero: round 2's behaviour
     eng2.forward_tiles(x)
-    assert eng2.range_overflow() and not eng2.range_overflow()                          # reported once, then reset
+    assert eng2.range_flag() & 1 and not eng2.range_overflow()                          # reported once, then reset
     eng2.set_precision("f32")
     ref = oseg.unet_forward(x.cpu(), big).numpy()
     assert _rel(eng2.forward_tiles(x).cpu().numpy(), ref) < REL                        # the exact mode is unaffected
+    # calibrated (the default), the same checkpoint is simply inside the window: per-layer power-of-two activation exponents
+    eng3 = UNetEngine(big, precision="fp16x3")
+    got = eng3.forward_tiles(x).cpu().numpy()
+    assert not eng3.range_overflow() and eng3.act_exponents()[0][0] < -5
+    assert _rel(got, ref) < REL
+    eng3.forward_tiles(x * 200.0)                                                       # ... until an input 200 x louder than the calibration input arrives
+    assert eng3.range_flag() & 1
 
 
 @pytest.mark.parametrize("opts", [{"sres_mrep": 2}, {"sres_ring": 1}, {"xcd_group": 0}, {"xcd_group": 7}, {"sres": 0}, {"fuse_first": 0}, {"b_lds": 1}])
