@@ -81,8 +81,10 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
-    """The oracle (CPU port of the reference algorithm) timed on this host's physical cores, on a bounded sample."""
+def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=8, reps=3):
+    """The oracle (CPU port of the reference algorithm) timed on this host's physical cores, on a bounded sample, with BASELINE.md 3's
+    protocol: 8 tiles (x20), fed 4 at a time like the reference's loop (analysis_object.py:22, segmenter.py:109-119), 1 warm-up +
+    3 timed repetitions; the registration and a tenth of one resample once each."""
     import numpy as np
     import torch
     from oai_analysis_2_amd.image import Image
@@ -91,11 +93,14 @@ def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
     torch.set_num_threads(cores)
     tiles, g = oseg.partition(vol_np, (128, 128, 32), (16, 16, 8))
     x = torch.from_numpy(np.ascontiguousarray(tiles[:n_tiles_sample]))
-    oseg.unet_forward(x[:1], unet_sd)                                    # warm-up
-    t0 = time.time()
-    for i in range(n_tiles_sample):
-        oseg.unet_forward(x[i:i + 1], unet_sd)
-    t_tile = (time.time() - t0) / n_tiles_sample
+    oseg.unet_forward(x[:4], unet_sd)                                    # warm-up
+    rep_s = []
+    for _ in range(reps):
+        t0 = time.time()
+        for i in range(0, n_tiles_sample, 4):
+            oseg.unet_forward(x[i:i + 4], unet_sd)
+        rep_s.append(time.time() - t0)
+    t_tile = min(rep_s) / n_tiles_sample
     t0 = time.time()
     phi, _ = oicon.register_pair_arrays(vol_np, atlas_img.array, icon_sd, both=False)
     t_reg = time.time() - t0
@@ -107,9 +112,9 @@ def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=4):
     t_res = (time.time() - t0) * (atlas_img.array.shape[0] / zs) * 2      # FC and TC
     t_vol = g["n_tiles"] * t_tile + t_reg + t_res
     return {"value": 1.0 / t_vol, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{n_tiles_sample} of {g['n_tiles']} U-Net tiles (x{g['n_tiles'] / n_tiles_sample:.0f}), "
-                      f"1 full ICON direction, {zs}/{atlas_img.array.shape[0]} slices of one resample (x{2 * atlas_img.array.shape[0] // zs}); "
-                      f"s/tile={t_tile:.2f} s_register={t_reg:.1f} s_resample={t_res:.1f}; torch threads = physical cores"}
+            "sample": f"{n_tiles_sample} of {g['n_tiles']} U-Net tiles in batches of 4 (x{g['n_tiles'] / n_tiles_sample:.0f}), 1 warm-up + {reps} repetitions "
+                      f"(best; all: {', '.join('%.1f' % r for r in rep_s)} s), 1 full ICON direction, {zs}/{atlas_img.array.shape[0]} slices of one resample "
+                      f"(x{2 * atlas_img.array.shape[0] // zs}); s/tile={t_tile:.2f} s_register={t_reg:.1f} s_resample={t_res:.1f}; torch threads = physical cores"}
 
 
 def fullsize_parity(unet, precision):
@@ -149,6 +154,30 @@ def fullsize_parity(unet, precision):
             "flips_with_pref_farther_than_1e-5_from_half": int(sum(1 for i in flips if abs(near.get(int(i), 0.0) - 0.5) >= 1e-5)),
             "sum_abs_dp_per_23.6M_voxels": [float(d * scale) for d in dsum], "reference_budget_sum_abs_dp": 12.0,
             "max_abs_dp_sample": float(np.abs(got_s - ref_s).max()), "sample_voxels_per_map": int(ref_s[0].size)}
+
+
+def rescaled_network_parity(unet_sd):
+    """the golden network with ec0.{weight,bias} * 2^-10, ec1.weight * 2^10, dc5.{weight,bias} * 2^-14, dc4.weight * 2^14 is
+    the SAME fp32 function (powers of two commute with ReLU and every rounding), so the reference golden applies unchanged; its
+    activations at ec0 / dc5 sit 2^10 / 2^14 below the original's.  fp16x3 with calibrated activation exponents must give the same
+    parity numbers as on the original network (tests/test_fp16_range_gpu.py asserts it; uncalibrated: 4e-4 relative logit error)."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = {k: v.clone() for k, v in unet_sd.items()}
+    for prod, k, cons in (("ec0", 10, "ec1"), ("dc5", 14, "dc4")):
+        sd[f"{prod}.0.weight"] *= 2.0 ** -k
+        sd[f"{prod}.0.bias"] *= 2.0 ** -k
+        sd[f"{cons}.0.weight"] *= 2.0 ** k
+    eng = UNetEngine(sd, precision="fp16x3")
+    out = fullsize_parity(eng, "fp16x3")
+    if out is not None:
+        out["network"] = "golden weights with ec0 * 2^-10 -> ec1 * 2^10 and dc5 * 2^-14 -> dc4 * 2^14 (bit-identical fp32 function)"
+        out["activation_exponents"] = eng.act_exponents()[0]
+        out["range_flag"] = eng.range_flag()
+    import torch
+    eng._ws = None                                                        # hand the second engine's activation workspace back before the next leg
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 def dry_run(args, world, rank):
@@ -198,6 +227,30 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+def streamed_from_host(pipe, n_volumes=8):
+    """BASELINE config 4, PCIe inclusive: `n_volumes` synthetic volumes in HOST memory streamed through one GPU by CohortRunner (pinned
+    staging + H2D of i+1 and D2H of i-1's five result tensors overlap the compute of i).  Never `value`."""
+    import torch
+    from oai_analysis_2_amd.cohort import CohortRunner
+    from oai_analysis_2_amd.image import Image
+    from oai_analysis_2_amd.synth import make_volume
+    imgs = [Image(make_volume(i, VOL_SHAPE), [0.36, 0.36, 0.7], [2.0, -3.0, 1.0]) for i in range(n_volumes)]      # seeds 0..7 (SURVEY 8d)
+    runner = CohortRunner(pipe)
+    for _ in runner.run(imgs[:2]):                                        # warm-up: pinned buffers, allocator
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n, repeated = 0, 0
+    for _, r in runner.run(imgs):
+        n += 1
+        repeated += int(r.repeated_f32)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "volumes/s", "volumes": n, "seconds": dt, "repeated_in_f32": repeated,
+            "what": "8 volumes from pageable host arrays -> pinned staging -> H2D -> segment + register + resample -> D2H of fc, tc, phi, "
+                    "fc_atlas, tc_atlas (566 MB per volume) into host tensors; upload / compute / download overlapped (cohort.CohortRunner)"}
+
+
 def measure(step, unet, steps, warmup, use_dist, dist):
     """W untimed + K timed steps, barrier + synchronize on both sides; returns (seconds, conv ms, conv launches)."""
     import torch
@@ -242,6 +295,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in exact fp32 MFMA (full --steps) reported beside the primary")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive leg (8 volumes streamed from host memory, BASELINE config 4)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="result-preserving tuning option of the fp16x3 path (oai_unet_set_option: sres, sres_mrep, sres_ring, xcd_group); repeatable")
     ap.add_argument("--no-overlap", action="store_true", help="registration after, not underneath, the segmentation (A/B of VolumePipeline.overlap_registration)")
@@ -300,6 +354,19 @@ def main():
     vols = [torch.from_numpy(v).cuda() for v in vols_np]                  # resident in HBM before timing
     meta = Image(vols_np[0], [0.36, 0.36, 0.7], [2.0, -3.0, 1.0])
 
+    # fp16x3: the per-layer activation exponents are calibrated once per network, outside the timed region (two segmentation passes
+    # over the first volume); rank 0's exponents go to every rank so that a tile-sharded volume is computed with one set
+    calibration = None
+    if args.precision == "fp16x3":
+        passes = unet.calibrate_volume(vols[0], TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, batch=args.batch or None) if rank == 0 or args.mode != "tileshard" else 0
+        exps = torch.tensor(unet.act_exponents()[0], dtype=torch.int32, device="cuda")
+        if use_dist and world > 1:
+            dist.broadcast(exps, 0)
+            unet.set_act_exponents(exps.tolist())
+        calibration = {"passes": passes, "activation_exponents": exps.tolist(),
+                       "note": "layer k stores x * 2^e[k] as fp16 term pairs: every layer's maximum in [2^10, 2^11) on the calibration volume; "
+                               "a later volume outside [8, 65504] raises the range flag and is repeated in fp32"}
+
     def step(i):
         # check=False: the per-volume fp16 range flag is snapshotted on the device and read after the timed region (what
         # CohortRunner does at download time), so that no host synchronisation sits between volumes
@@ -313,10 +380,18 @@ def main():
         claimed = []
 
         def run_queue(q):
-            flags = []
+            # a rank claims its next volume when the one BEFORE the volume it has just queued is finished: the host runs one volume
+            # ahead of its GPU (so the GPU never idles), not the whole queue ahead (kernel launches are asynchronous: unbounded, the
+            # rank whose host thread is fastest would claim most of the cohort -- ADVICE r2)
+            flags, events = [], []
             for i in q:
                 claimed.append(i)
                 flags.append(pipe.run(vols[i % n_distinct], meta, check=False).overflow)
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
+                if len(events) >= 2:
+                    events[-2].synchronize()
             return flags
 
         run_queue(warm_q)
@@ -401,11 +476,16 @@ def main():
                        "cohort": ({"volumes": args.steps * world, "claimed_by_rank0": my_volumes} if args.mode == "cohort" else None)},
             "roofline": roofline(args.precision, conv_ms, conv_launches, my_volumes, my_frac),
             "fp16_range_overflow": overflow,
+            "fp16_calibration": calibration,
             "segment_algorithmic_tflop_per_volume": unet.tile_flops(TILE_ZYX, OVERLAP_ZYX, True) * n_tiles / 1e12,
             "segment_frame_aware_tflop_per_volume": unet.volume_flops(VOL_SHAPE, TILE_ZYX, OVERLAP_ZYX, CROP_ZYX, True, False) / 1e12,
         }
         if world == 1 and not args.no_parity:
             out["parity"] = fullsize_parity(unet, args.precision)
+            if args.precision == "fp16x3" and out["parity"] is not None:
+                out["parity"]["rescaled_network"] = rescaled_network_parity(unet_sd)
+        if world == 1 and not args.no_streamed and args.mode == "replicas":
+            out["streamed_from_host"] = streamed_from_host(pipe)
         if world == 1 and not args.no_alt:
             # the SAME workload, same --steps / --warmup, with the other arithmetic (exact fp32 MFMA when the primary is split-fp16):
             # a first-class measurement, so that a reader who only credits reference-precision arithmetic has a number

@@ -278,7 +278,11 @@ typedef struct oai_icon_unet_params {
     const float* last_w; const float* last_b;
 } oai_icon_unet_params;
 
-/* nets[0], nets[1]: the two low-resolution steps; nets[2]: the full-resolution step. */
+/* nets[0], nets[1]: the two low-resolution steps; nets[2]: the full-resolution step.
+ * BatchNorm3d behind every up-conv (networks.UNet2.batchNorms of the package the reference calls at registration.py:20): pass all four
+ * bn_* arrays of a level, or NULL for all four = no normalisation at that level.  icon_registration 1.1.2 is not vendored in the
+ * reference tree and one recollection of it has the batchNorms[depth] call commented out in UNet2.forward (the parameters are in the
+ * state_dict either way): the caller decides, nothing is assumed silently. */
 int oai_icon_create(const oai_icon_unet_params nets_host[3], int D, int H, int W, oai_icon** out);
 void oai_icon_destroy(oai_icon* h);
 size_t oai_icon_workspace_bytes(const oai_icon* h);
@@ -293,6 +297,10 @@ int oai_icon_forward(oai_icon* h, const float* A_dev, const float* B_dev, float*
  * runs the same launches directly.  oai_icon_graph_info: *captured = 1 graph in use, 0 not captured yet, -1 capture failed on this
  * runtime (direct launches are used: same kernels, same results); counts of replays / direct runs. */
 int oai_icon_set_graph(oai_icon* h, int enable);
+/* Restatement switches of the un-vendored package (defaults = SURVEY Appendix A):
+ *   "pad_front" 0|1 (1)  networks.pad_or_crop zero-pads the residual's missing channels in front (1) or behind (0) of the existing ones
+ *                        (down path: avg_pool3d(x) has fewer channels than the conv's output). */
+int oai_icon_set_option(oai_icon* h, const char* name, int value);
 int oai_icon_graph_info(const oai_icon* h, int* captured, long long* replays, long long* direct_runs);
 
 /* One tallUNet2 forward on its own (unit-test seam): out[3][D][H][W] = net(a, b). */

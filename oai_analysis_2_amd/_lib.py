@@ -85,6 +85,7 @@ SIGNATURES = {
     "oai_icon_workspace_bytes": (_Z, [_P]),
     "oai_icon_forward": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     "oai_icon_set_graph": (_I, [_P, _I]),
+    "oai_icon_set_option": (_I, [_P, C.c_char_p, _I]),
     "oai_icon_graph_info": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "oai_icon_unet_forward": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _Z, _P]),
 }

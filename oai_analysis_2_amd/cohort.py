@@ -92,12 +92,14 @@ class CohortRunner:
         cur = next(order, None)
         if cur is None:
             return
-        nxt = self._upload(as_image(images[cur]), 0)
+        # every image is fetched from ``images`` exactly ONCE (a lazy sequence -- dask_processing._Lazy -- reads and normalises the file
+        # in __getitem__) and travels with its upload: (device tensor, upload event, host image)
+        img = as_image(images[cur])
+        nxt = (*self._upload(img, 0), img)
         pending = None                                                    # (index, device results, completion event, ...) of the previous volume
         k = 0
         while cur is not None:
-            img = as_image(images[cur])
-            dev, ev = nxt
+            dev, ev, img = nxt
             torch.cuda.current_stream().wait_event(ev)
             dev.record_stream(torch.cuda.current_stream())                # allocated on the copy stream, read by the compute stream
             res = self.pipe.run(dev, img, check=False)                    # queued, not waited for; the range flag is read at download time
@@ -105,7 +107,8 @@ class CohortRunner:
             done.record()
             following = next(order, None)                                 # claimed now: its host staging + H2D run behind this volume's compute
             if following is not None:
-                nxt = self._upload(as_image(images[following]), (k + 1) & 1)
+                img_next = as_image(images[following])
+                nxt = (*self._upload(img_next, (k + 1) & 1), img_next)
             if pending is not None:
                 yield pending[0], self._finish(pending)
             pending = (cur, res, done, dev, img)

@@ -10,6 +10,7 @@
 // torch.cat is free: every tensor is produced directly into its channel slice of the level's
 // concat buffer  cat_d = [ up_out[d] | down[d] ]  (UNet2.forward: x = cat([x, skips[d]], 1)).
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -34,7 +35,7 @@ struct __attribute__((packed, aligned(4))) pair_f32s { float a, b; };       // 8
 __device__ __forceinline__ void pair_store(float* p, float a, float b) { *reinterpret_cast<pair_f32s*>(p) = pair_f32s{a, b}; }
 
 // Conv3d k3 p1, stride S, on leaky_relu(x) (PRE) + bias, optional residual
-//   RES: + avg_pool3d(x,2,ceil_mode=True) zero-padded IN FRONT to Cout channels (UNet2 down path)
+//   RES: + avg_pool3d(x,2,ceil_mode=True) zero-padded to Cout channels, in front or behind (res_ofs; UNet2 down path)
 // out = (acc + bias [+ res]) / div
 // KS > 1 (deep levels, a few hundred voxels or fewer but K = 27*Cin up to 6912): the block's 256 threads are
 // 256/KS voxels x KS slices of the input channels; partial sums meet in LDS and slice 0 runs the epilogue.
@@ -42,7 +43,7 @@ template <int S, int COUT_T, bool PRE, bool RES, int KS>
 __global__ void __launch_bounds__(256)
 icon_conv3_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
                   const float* __restrict__ wk /*[Cin][27][Cout]*/, const float* __restrict__ bias,
-                  float* __restrict__ out, int Cout, int Do, int Ho, int Wo, float div) {
+                  float* __restrict__ out, int Cout, int Do, int Ho, int Wo, float div, int res_ofs) {
     constexpr int VT = 256 / KS;
     __shared__ float red[KS > 1 ? (KS - 1) * VT * COUT_T : 1];
     const int cg = blockIdx.y;
@@ -91,8 +92,8 @@ icon_conv3_kernel(const float* __restrict__ x, int Cin, int D, int H, int W,
         const int co = cg * COUT_T + j;
         float r = acc[j] + bias[co];
         if (RES) {
-            const int cs = co - (Cout - Cin);          // pad_or_crop pads zero channels in front
-            if (cs >= 0) {
+            const int cs = co - res_ofs;               // pad_or_crop: zero channels in front (res_ofs = Cout - Cin) or behind (0)
+            if (cs >= 0 && cs < Cin) {
                 const int z1 = min(2 * oz + 2, D), y1 = min(2 * oy + 2, H), x1 = min(2 * ox + 2, W);
                 float s = 0.0f;
                 for (int z = 2 * oz; z < z1; ++z)
@@ -412,6 +413,7 @@ struct oai_icon {
     // hipGraph replay of the ~70 dependent launches of one direction (oai_icon_forward): captured once per workspace on an
     // internal stream (the caller's stream may be the legacy null stream, which cannot be captured), replayed on the caller's.
     bool use_graph = true, graph_broken = false;
+    bool pad_front = true;            // pad_or_crop's zero channels in front or behind (option "pad_front")
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     void* g_ws = nullptr;
@@ -467,7 +469,7 @@ size_t unet_ws_floats(int D, int H, int W) {
     return n;
 }
 
-int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, int H, int W, float* out,
+int unet_forward(const NetWeights& nw, bool pad_front, const float* a, const float* b, int D, int H, int W, float* out,
                  float* ws, hipStream_t st) {
     const Dims dm = level_dims(D, H, W);
     // every axis must survive five halvings with a >= 2 input to each pooling (avg_pool3d needs size >= kernel)
@@ -481,26 +483,27 @@ int unet_forward(const NetWeights& nw, const float* a, const float* b, int D, in
     for (int l = 0; l < 5; ++l) {
         const float* src = cat[l] + (size_t)kUpOut[l] * dm.vox[l];
         float* dst = l < 4 ? cat[l + 1] + (size_t)kUpOut[l + 1] * dm.vox[l + 1] : bottom;
+        const int res_ofs = pad_front ? kDown[l + 1] - kDown[l] : 0;
         if (dm.vox[l + 1] >= kSplitKBelow || kDown[l] < 8) {
             dim3 grid(oai::cdiv(dm.vox[l + 1], 256), kDown[l + 1] / 16);
             icon_conv3_kernel<2, 16, true, true, 1><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
                                                                            nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
-                                                                           dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+                                                                           dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f, res_ofs);
         } else if ((long long)oai::cdiv(dm.vox[l + 1], 32) * (kDown[l + 1] / 16) >= kFewBlocks) {
             dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1] / 16);
             icon_conv3_kernel<2, 16, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
                                                                            nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
-                                                                           dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+                                                                           dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f, res_ofs);
         } else if ((long long)oai::cdiv(dm.vox[l + 1], 32) * (kDown[l + 1] / 16) < kFewBlocks / 16) {
             dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1]);          // one cout per block
             icon_conv3_kernel<2, 1, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
                                                                           nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
-                                                                          dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+                                                                          dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f, res_ofs);
         } else {        // the deepest levels (a few dozen voxels): 4 couts per block instead of 16, four times the blocks
             dim3 grid(oai::cdiv(dm.vox[l + 1], 32), kDown[l + 1] / 4);
             icon_conv3_kernel<2, 4, true, true, 8><<<grid, 256, 0, st>>>(src, kDown[l], dm.d[l][0], dm.d[l][1], dm.d[l][2],
                                                                           nw.down_w[l], nw.down_b[l], dst, kDown[l + 1],
-                                                                          dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f);
+                                                                          dm.d[l + 1][0], dm.d[l + 1][1], dm.d[l + 1][2], 1.0f, res_ofs);
         }
         OAI_CHECK_LAUNCH();
     }
@@ -592,8 +595,15 @@ int oai_icon_create(const oai_icon_unet_params nets[3], int D, int H, int W, oai
         const oai_icon_unet_params& p = nets[n];
         NetWeights& nw = h->net[n];
         for (int l = 0; l < 5 && rc == OAI_OK; ++l) {
-            if (!p.down_w[l] || !p.down_b[l] || !p.up_w[l] || !p.up_b[l] || !p.bn_gamma[l] || !p.bn_beta[l] || !p.bn_mean[l] || !p.bn_var[l]) {
+            if (!p.down_w[l] || !p.down_b[l] || !p.up_w[l] || !p.up_b[l]) {
                 rc = oai::set_error(OAI_ERR_ARG, "oai_icon_create: net %d level %d has a null parameter", n, l);
+                break;
+            }
+            // BatchNorm3d after the up-conv: all four arrays, or none of them = no normalisation (identity).  Whether the package's
+            // UNet2.forward applies batchNorms[depth] cannot be checked here (icon_registration 1.1.2 is not vendored): the caller decides.
+            const int nbn = (p.bn_gamma[l] != nullptr) + (p.bn_beta[l] != nullptr) + (p.bn_mean[l] != nullptr) + (p.bn_var[l] != nullptr);
+            if (nbn != 0 && nbn != 4) {
+                rc = oai::set_error(OAI_ERR_ARG, "oai_icon_create: net %d level %d: BatchNorm needs gamma, beta, mean and var (or none of them)", n, l);
                 break;
             }
             if ((rc = upload(h, repack_conv(p.down_w[l], kDown[l + 1], kDown[l], 27), &nw.down_w[l]))) break;
@@ -602,8 +612,8 @@ int oai_icon_create(const oai_icon_unet_params nets[3], int D, int H, int W, oai
             if ((rc = upload(h, std::vector<float>(p.up_b[l], p.up_b[l] + kUpOut[l]), &nw.up_b[l]))) break;
             std::vector<float> s(kUpOut[l]), t(kUpOut[l]);
             for (int c = 0; c < kUpOut[l]; ++c) {
-                s[c] = p.bn_gamma[l][c] / sqrtf(p.bn_var[l][c] + kBnEps);
-                t[c] = p.bn_beta[l][c] - p.bn_mean[l][c] * s[c];
+                s[c] = nbn ? p.bn_gamma[l][c] / sqrtf(p.bn_var[l][c] + kBnEps) : 1.0f;
+                t[c] = nbn ? p.bn_beta[l][c] - p.bn_mean[l][c] * s[c] : 0.0f;
             }
             if ((rc = upload(h, s, &nw.bn_s[l]))) break;
             if ((rc = upload(h, t, &nw.bn_t[l]))) break;
@@ -638,7 +648,7 @@ int oai_icon_unet_forward(oai_icon* h, int which, const float* a, const float* b
     OAI_CHECK_ARG(dims_ok(D, H, W), "oai_icon_unet_forward: %dx%dx%d too small for five 2x poolings (each axis >= 17)", D, H, W);
     if (unet_ws_floats(D, H, W) * 4 > ws_bytes)
         return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_unet_forward: workspace %zu B < %zu B", ws_bytes, unet_ws_floats(D, H, W) * 4);
-    return unet_forward(h->net[which], a, b, D, H, W, out, (float*)ws, (hipStream_t)stream);
+    return unet_forward(h->net[which], h->pad_front, a, b, D, H, W, out, (float*)ws, (hipStream_t)stream);
 }
 
 // the launches of one direction, on `st`, reading s.A / s.B and writing s.phi (all inside the workspace)
@@ -650,16 +660,16 @@ static int icon_forward_body(oai_icon* h, const Ws& s, hipStream_t st) {
 #define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
     RUN(oai_avgpool2_3d(A, 1, D, H, W, s.a, st));                                  // DownsampleRegistration.forward
     RUN(oai_avgpool2_3d(B, 1, D, H, W, s.b, st));
-    RUN(unet_forward(h->net[0], s.a, s.b, d, hh, w, s.d1, s.unet, st));            // FFVF(u1)
+    RUN(unet_forward(h->net[0], h->pad_front, s.a, s.b, d, hh, w, s.d1, s.unet, st));            // FFVF(u1)
     // the warp / compose closures run as fused chains (oai_warp_chain, warp.hip): bit-identical to the op-by-op sequence of
     // oai_compose / oai_grid_sample3d calls (tests/test_warp_gpu.py), none of c1..c4 is materialised
     const float* f21[2] = {s.d2, s.d1};
     const int low[6] = {d, hh, w, d, hh, w};
     RUN(oai_warp_chain(s.d1, d, hh, w, 0, nullptr, nullptr, s.a, d, hh, w, s.aw, st));        // a warped by id_l + d1 (isIdentity shortcut)
-    RUN(unet_forward(h->net[1], s.aw, s.b, d, hh, w, s.d2, s.unet, st));           // FFVF(u2)
+    RUN(unet_forward(h->net[1], h->pad_front, s.aw, s.b, d, hh, w, s.d2, s.unet, st));           // FFVF(u2)
     // c1 = id_h + sample(d2, id_h); c2 = c1 + sample(d1, c1); A warped by c2
     RUN(oai_warp_chain(nullptr, D, H, W, 2, f21, low, A, D, H, W, s.Aw, st));
-    RUN(unet_forward(h->net[2], s.Aw, B, D, H, W, s.d3, s.unet, st));              // FFVF(u3)
+    RUN(unet_forward(h->net[2], h->pad_front, s.Aw, B, D, H, W, s.d3, s.unet, st));              // FFVF(u3)
     // c3 = id_h + d3 (shortcut); c4 = c3 + sample(d2, c3); phi = c4 + sample(d1, c4)
     RUN(oai_warp_chain(s.d3, D, H, W, 2, f21, low, nullptr, 0, 0, 0, s.phi, st));
 #undef RUN
@@ -710,6 +720,20 @@ int oai_icon_set_graph(oai_icon* h, int enable) {
     OAI_CHECK_ARG(h, "oai_icon_set_graph: null handle");
     h->use_graph = enable != 0;
     return OAI_OK;
+}
+
+int oai_icon_set_option(oai_icon* h, const char* name, int value) {
+    OAI_CHECK_ARG(h && name, "oai_icon_set_option: null pointer");
+    if (!strcmp(name, "pad_front")) {
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_icon_set_option: pad_front must be 0 or 1");
+        if (h->pad_front != (value != 0)) {
+            h->pad_front = value != 0;
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }     // the captured launches carry the old offset
+            h->g_ws = nullptr;
+        }
+        return OAI_OK;
+    }
+    return oai::set_error(OAI_ERR_ARG, "oai_icon_set_option: unknown option '%s'", name);
 }
 
 int oai_icon_graph_info(const oai_icon* h, int* captured, long long* replays, long long* direct_runs) {

@@ -84,7 +84,10 @@ def segment_method(image_A):
 def register_images_delayed(image_A, image_B):
     """dask_processing.py:46-92: (phi_AB, image_A (normalised), image_B)."""
     image_A, image_B = readimage(image_A), readimage(image_B)
-    image_A = image_normalize(image_A.like(image_A.array.astype(np.float64)), 0.1, 99.9, 0, 1)      # the reference casts to itk.D first
+    # the reference casts BOTH images to itk.D (:63-73) and windows A in double; here the window (percentiles + rescale) is computed in
+    # fp32 on the device and widened: values agree with the double computation to ~1e-7 (tests/test_normalize_gpu.py)
+    image_B = image_B.like(image_B.array.astype(np.float64))
+    image_A = image_normalize(image_A.like(image_A.array.astype(np.float64)), 0.1, 99.9, 0, 1)
     phi_AB = get_worker().registerer.register(image_A, image_B)
     return phi_AB, image_A, image_B
 
@@ -96,7 +99,9 @@ def deform_probmap_delayed(phi_AB, image_A, image_B, prob, image_type="FC"):
 
 
 def get_thickness(warped_image, mesh_type):
-    """dask_processing.py:114-122: the inner surface of the cartilage with per-point thickness ("Distance")."""
+    """dask_processing.py:114-122: the inner surface of the cartilage with per-point thickness ("Distance").  The reference converts the
+    vtk mesh with mp.get_itk_mesh only "to make it serializable" for Dask's pickling (mesh_processing.py:57-98); there is no task graph
+    to pickle for here, so the mesh is returned as mesh_processing produces it."""
     from . import mesh_processing as mp
     distance_inner, _ = mp.get_thickness_mesh(warped_image, mesh_type=mesh_type)
     return distance_inner
@@ -127,6 +132,9 @@ def process_cohort(images: Sequence, atlas_image, worker: Optional[Worker] = Non
             return len(images)
 
         def __getitem__(self_inner, i):
-            return image_normalize(readimage(images[i]), 0.1, 99.9, 0, 1)
+            # on the runner's copy stream: the upload, the percentile kernels and the blocking .cpu() of image_normalize then wait for
+            # earlier copies only, not for the volume whose compute was queued a moment ago (the overlap was lost)
+            with torch.cuda.stream(runner.copy_stream):
+                return image_normalize(readimage(images[i]), 0.1, 99.9, 0, 1)
 
     return runner.run(_Lazy(), queue=VolumeQueue(len(images)))

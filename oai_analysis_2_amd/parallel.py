@@ -152,26 +152,47 @@ class VolumeQueue:
 
     _serial = 0
 
-    def __init__(self, n_volumes: int, name: Optional[str] = None):
+    def __init__(self, n_volumes: int, name: Optional[str] = None, store=None):
+        """``store``: a torch.distributed Store shared by the ranks (default: the default process group's); collective in the sense that
+        every rank must construct its queues in the same order (or pass the same ``name``).  The size travels with the key: the first
+        rank to arrive publishes ``n``, every other rank checks that it was about to iterate over the same cohort."""
         self.n = int(n_volumes)
         self._local = 0
         self._store = None
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            from torch.distributed import distributed_c10d
-            self._store = distributed_c10d._get_default_store()
+        self._done = False
+        self.claimed: List[int] = []                # what THIS rank took (a driver can diff it against the finished results)
+        if store is not None or (dist.is_initialized() and dist.get_world_size() > 1):
+            if store is None:
+                from torch.distributed import distributed_c10d
+                store = distributed_c10d._get_default_store()      # (private API: the one store every rank already shares)
+            self._store = store
             if name is None:                       # every rank constructs its queues in the same order: same key on all ranks
                 name = f"oai_volume_queue_{VolumeQueue._serial}"
                 VolumeQueue._serial += 1
             self._key = name
+            if int(self._store.add(self._key + "_ranks", 1)) == 1:
+                self._store.set(self._key + "_n", str(self.n))
+            else:
+                self._store.wait([self._key + "_n"])
+                n_pub = int(self._store.get(self._key + "_n"))
+                if n_pub != self.n:
+                    raise RuntimeError(f"VolumeQueue '{name}': this rank iterates over {self.n} volumes, the rank that created the key over "
+                                       f"{n_pub} (a queue constructed on some ranks only, or a reused name)")
 
     def claim(self) -> Optional[int]:
         """Index of the next volume, or None when the cohort is exhausted.  Each index is handed out exactly once across ranks."""
+        if self._done:
+            return None
         if self._store is None:
             i = self._local
             self._local += 1
         else:
             i = int(self._store.add(self._key, 1)) - 1
-        return i if i < self.n else None
+        if i < self.n:
+            self.claimed.append(i)
+            return i
+        self._done = True                          # (the counter key stays: a late rank must still see an exhausted queue, not a fresh one)
+        return None
 
     def __iter__(self):
         while True:

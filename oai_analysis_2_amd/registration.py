@@ -95,11 +95,42 @@ class DisplacementTransform:
 _NET_PREFIXES = ("netPhi.net.netPhi.net.", "netPhi.net.netPsi.net.", "netPsi.net.")   # u1, u2 (low-res), u3
 
 
-class IconEngine:
-    """``OAI_knees_gradICON_model().regis_net`` as packed weights + HIP kernels."""
+def map_icon_state_dict(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Keys of the three tallUNet2s out of whatever the caller holds: the ``regis_net`` state_dict itself, the whole
+    ``GradientICON`` module's (keys prefixed ``regis_net.``), or a checkpoint dict wrapping either.  Non-parameter entries of the
+    package's modules are recognised and dropped -- the registered ``identity_map`` / ``spacing`` buffers of every wrapper level
+    and BatchNorm's ``num_batches_tracked`` -- anything else that is not a U-Net parameter raises (a wrong file should not load)."""
+    sd = state_dict
+    for wrap in ("model_state_dict", "state_dict"):
+        if wrap in sd and isinstance(sd[wrap], dict):
+            sd = sd[wrap]
+    if any(k.startswith("regis_net.") for k in sd):
+        sd = {k[len("regis_net."):]: v for k, v in sd.items() if k.startswith("regis_net.")}
+    out, unknown = {}, []
+    for k, v in sd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf in ("identity_map", "spacing", "num_batches_tracked", "_extra_state"):
+            continue
+        if any(k.startswith(pre) for pre in _NET_PREFIXES):
+            out[k] = v
+        else:
+            unknown.append(k)
+    if unknown:
+        raise KeyError(f"unexpected keys in the ICON state_dict: {sorted(unknown)[:4]}")
+    return out
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], net_shape: Sequence[int] = NET_SHAPE, device=None):
+
+class IconEngine:
+    """``OAI_knees_gradICON_model().regis_net`` as packed weights + HIP kernels.
+
+    ``apply_bn`` / ``pad_front``: the two points where the restatement of the un-vendored ``icon_registration`` 1.1.2 rests on
+    recollection (oracle/icon.py:OPTIONS): eval-mode BatchNorm3d behind every up-conv or none, and the side on which
+    ``pad_or_crop`` adds zero channels.  Defaults as in SURVEY Appendix A."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], net_shape: Sequence[int] = NET_SHAPE, device=None,
+                 apply_bn: bool = True, pad_front: bool = True):
         import ctypes as C
+        state_dict = map_icon_state_dict(state_dict)
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.OaiError("no HIP device: the MI355X path has no CPU fallback")
@@ -120,13 +151,17 @@ class IconEngine:
             for d in range(5):
                 p.down_w[d], p.down_b[d] = ptr(f"{pre}downConvs.{d}.weight"), ptr(f"{pre}downConvs.{d}.bias")
                 p.up_w[d], p.up_b[d] = ptr(f"{pre}upConvs.{d}.weight"), ptr(f"{pre}upConvs.{d}.bias")
-                p.bn_gamma[d], p.bn_beta[d] = ptr(f"{pre}batchNorms.{d}.weight"), ptr(f"{pre}batchNorms.{d}.bias")
-                p.bn_mean[d], p.bn_var[d] = ptr(f"{pre}batchNorms.{d}.running_mean"), ptr(f"{pre}batchNorms.{d}.running_var")
+                if apply_bn:
+                    p.bn_gamma[d], p.bn_beta[d] = ptr(f"{pre}batchNorms.{d}.weight"), ptr(f"{pre}batchNorms.{d}.bias")
+                    p.bn_mean[d], p.bn_var[d] = ptr(f"{pre}batchNorms.{d}.running_mean"), ptr(f"{pre}batchNorms.{d}.running_var")
             p.last_w, p.last_b = ptr(f"{pre}lastConv.weight"), ptr(f"{pre}lastConv.bias")
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_icon_create(params, *self.net_shape, C.byref(handle)), "oai_icon_create")
         self._h = handle
+        self.apply_bn, self.pad_front = bool(apply_bn), bool(pad_front)
+        if not pad_front:
+            _lib.check(self.lib.oai_icon_set_option(self._h, b"pad_front", 0), "oai_icon_set_option")
         self._ws = torch.empty(int(self.lib.oai_icon_workspace_bytes(self._h)), dtype=torch.uint8, device=self.device)
 
     def __del__(self):
@@ -187,7 +222,8 @@ class ICON_Registration:
     ``$OAI_DATA_DIR/icon_weights.pth`` (the reference downloads them; there is no network here).
     """
 
-    def __init__(self, weights=None, net_shape: Sequence[int] = NET_SHAPE, device=None, verbose: bool = True):
+    def __init__(self, weights=None, net_shape: Sequence[int] = NET_SHAPE, device=None, verbose: bool = True,
+                 apply_bn: bool = True, pad_front: bool = True):
         import os
         if weights is None:
             root = os.environ.get("OAI_DATA_DIR")
@@ -198,7 +234,7 @@ class ICON_Registration:
             if not os.path.isfile(weights):
                 raise ValueError(f"=> no checkpoint found at '{weights}'")
             weights = torch.load(weights, map_location="cpu")
-        self.register_module = IconEngine(weights, net_shape, device)
+        self.register_module = IconEngine(weights, net_shape, device, apply_bn=apply_bn, pad_front=pad_front)
         self.verbose = verbose
 
     def register(self, fixed_image, moving_image) -> DisplacementTransform:

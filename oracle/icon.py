@@ -44,30 +44,42 @@ U2 = "netPhi.net.netPsi.net."       # low-res step 2
 U3 = "netPsi.net."                   # full-res step
 
 
-def _pad_or_crop_channels(x: torch.Tensor, c: int) -> torch.Tensor:
-    """``networks.pad_or_crop``: keep the first ``c`` channels, or zero-pad IN FRONT up to ``c``."""
+# Two points of the restatement rest on recollection of the un-vendored package and can be recalled differently (SURVEY App. A;
+# VERDICT r2 missing #4): whether ``UNet2.forward`` applies ``batchNorms[depth]`` (the ModuleList exists either way, so the keys are
+# in the state_dict) and on which side ``pad_or_crop`` puts the zero channels.  Both are switches here and in the library
+# (oai_icon_create: bn_* == NULL; oai_icon_set_option "pad_front"), tested in all four combinations; the defaults are SURVEY's.
+OPTIONS = {"apply_bn": True, "pad_front": True}
+
+
+def _pad_or_crop_channels(x: torch.Tensor, c: int, pad_front: bool = True) -> torch.Tensor:
+    """``networks.pad_or_crop``: keep the first ``c`` channels, or zero-pad (in front, or behind) up to ``c``."""
     y = x[:, :c]
     if x.shape[1] < c:
-        y = F.pad(y, (0, 0, 0, 0, 0, 0, c - x.shape[1], 0))
+        n = c - x.shape[1]
+        y = F.pad(y, (0, 0, 0, 0, 0, 0, n, 0) if pad_front else (0, 0, 0, 0, 0, 0, 0, n))
     return y
 
 
 @torch.no_grad()
-def tall_unet2(a: torch.Tensor, b: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = "") -> torch.Tensor:
-    """``UNet2(5, [[2,16,32,64,256,512],[16,32,64,128,256]], 3).forward(a, b)`` -> [B,3,D,H,W]."""
+def tall_unet2(a: torch.Tensor, b: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str = "", apply_bn=None, pad_front=None) -> torch.Tensor:
+    """``UNet2(5, [[2,16,32,64,256,512],[16,32,64,128,256]], 3).forward(a, b)`` -> [B,3,D,H,W].  ``apply_bn`` / ``pad_front``:
+    None = the module-level OPTIONS."""
+    apply_bn = OPTIONS["apply_bn"] if apply_bn is None else apply_bn
+    pad_front = OPTIONS["pad_front"] if pad_front is None else pad_front
     x = torch.cat([a, b], 1)
     skips = []
     for d in range(5):
         skips.append(x)
         y = F.conv3d(F.leaky_relu(x, LEAKY), sd[f"{prefix}downConvs.{d}.weight"], sd[f"{prefix}downConvs.{d}.bias"],
                      stride=2, padding=1)
-        x = y + _pad_or_crop_channels(F.avg_pool3d(x, 2, ceil_mode=True), y.shape[1])
+        x = y + _pad_or_crop_channels(F.avg_pool3d(x, 2, ceil_mode=True), y.shape[1], pad_front)
     for d in reversed(range(5)):
         y = F.conv_transpose3d(F.leaky_relu(x, LEAKY), sd[f"{prefix}upConvs.{d}.weight"], sd[f"{prefix}upConvs.{d}.bias"],
                                stride=2, padding=1)
-        x = y + F.interpolate(_pad_or_crop_channels(x, y.shape[1]), scale_factor=2, mode="trilinear", align_corners=False)
-        x = F.batch_norm(x, sd[f"{prefix}batchNorms.{d}.running_mean"], sd[f"{prefix}batchNorms.{d}.running_var"],
-                         sd[f"{prefix}batchNorms.{d}.weight"], sd[f"{prefix}batchNorms.{d}.bias"], training=False, eps=BN_EPS)
+        x = y + F.interpolate(_pad_or_crop_channels(x, y.shape[1], pad_front), scale_factor=2, mode="trilinear", align_corners=False)
+        if apply_bn:
+            x = F.batch_norm(x, sd[f"{prefix}batchNorms.{d}.running_mean"], sd[f"{prefix}batchNorms.{d}.running_var"],
+                             sd[f"{prefix}batchNorms.{d}.weight"], sd[f"{prefix}batchNorms.{d}.bias"], training=False, eps=BN_EPS)
         s = skips[d]
         x = x[:, :, :s.shape[2], :s.shape[3], :s.shape[4]]
         x = torch.cat([x, s], 1)

@@ -80,3 +80,38 @@ def test_graph_replay_equals_direct_launches():
     assert captured == 1 and replays == 3 and direct_runs == 0, (captured, replays, direct_runs)
     assert torch.equal(got1, ref) and torch.equal(got3, ref)
     assert torch.equal(got2, direct.phi(B, A))
+
+
+@pytest.mark.parametrize("apply_bn", [True, False])
+@pytest.mark.parametrize("pad_front", [True, False])
+def test_restatement_switches_match_the_oracle_both_ways(apply_bn, pad_front):
+    """The two recollection-dependent points of the un-vendored package (VERDICT r2 missing #4): eval BatchNorm behind the up-convs or
+    none (oai_icon_create: bn_* == NULL), zero channels of pad_or_crop in front or behind (oai_icon_set_option "pad_front").  Each of
+    the four combinations equals the oracle run with the same flags -- and differs from the others, so the switch is live."""
+    from oai_analysis_2_amd.registration import IconEngine
+    sd = make_icon_state_dict(3)
+    net = (40, 48, 48)
+    shape = (33, 45, 37)
+    a, b = make_volume(1, shape), make_volume(2, shape)
+    eng = IconEngine(sd, net_shape=net, apply_bn=apply_bn, pad_front=pad_front)
+    ta, tb = torch.from_numpy(a)[None, None], torch.from_numpy(b)[None, None]
+    for which, pre in enumerate((oicon.U1, oicon.U3)):
+        which = which * 2
+        ref = oicon.tall_unet2(ta, tb, sd, pre, apply_bn=apply_bn, pad_front=pad_front)[0].numpy()
+        got = eng.unet(which, torch.from_numpy(a), torch.from_numpy(b)).cpu().numpy()
+        assert _rel(got, ref) < TOL, (which, _rel(got, ref))
+        other = oicon.tall_unet2(ta, tb, sd, pre, apply_bn=not apply_bn, pad_front=pad_front)[0].numpy()
+        other2 = oicon.tall_unet2(ta, tb, sd, pre, apply_bn=apply_bn, pad_front=not pad_front)[0].numpy()
+        assert _rel(got, other) > 100 * TOL and _rel(got, other2) > 100 * TOL
+    # the whole direction (graph replay included) with the same flags
+    A, B = make_volume(5, net), make_volume(6, net)
+    old = dict(oicon.OPTIONS)
+    try:
+        oicon.OPTIONS.update(apply_bn=apply_bn, pad_front=pad_front)
+        ref = oicon.regis_net_direction(torch.from_numpy(A)[None, None], torch.from_numpy(B)[None, None], sd)[0].numpy()
+    finally:
+        oicon.OPTIONS.update(old)
+    ident = oicon.identity_map(net)[0].numpy()
+    for _ in range(2):                                       # second call = graph replay
+        got = eng.phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy()
+        assert _rel(got - ident, ref - ident) < TOL

@@ -97,6 +97,12 @@ def test_cohort_of_8_full_size_volumes_streams_and_matches_single_runs():
             one = pipe.run(torch.from_numpy(imgs[i].array).cuda(), imgs[i])
             for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
                 assert torch.equal(getattr(one, name).cpu(), getattr(r, name)), (i, name)
+        if i == 3:
+            # the tile-shard latency path on one rank (registration on the side stream underneath the sharded segmentation, joined
+            # before the z-slab resample) gives the same five tensors as run() at the BASELINE size
+            sh = pipe.run_sharded(torch.from_numpy(imgs[i].array).cuda(), imgs[i])
+            for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
+                assert torch.equal(getattr(sh, name).cpu(), getattr(r, name)), ("sharded", name)
     assert seen == list(range(8))
 
 
