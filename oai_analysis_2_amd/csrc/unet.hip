@@ -53,6 +53,7 @@ struct oai_unet {
     // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
     int act_exp[18] = {0};
     bool calibrated = false;
+    int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
     int xcd_group = 32;                 // logical blocks per XCD deal (option "xcd_group"; 0 = launch order)
@@ -467,9 +468,11 @@ static bool first_fusable(const oai_unet* h, const Box& ec1_box) {
 
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
                         const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
-                        float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr) {
+                        float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr,
+                        const int* store_boxes = nullptr) {
     ConvArgs a;
     if (head) a = *head;                   // the fused dc0 fields (see ConvArgs); everything else is set below
+    if (store_boxes && h->sres && h->opt_dead_stores) { a.store_boxes = store_boxes; a.store_grow = 1; }
     if (first) {                           // ec0 fused into this layer's staging (first_fusable)
         a.first_w = h->L[EC0].plain; a.first_scale = h->L[EC0].scale_f16; a.first_shift = h->L[EC0].shift_f16; a.first_src = *first;   // (sres => fp16x3)
         a.first_census = h->opt_census ? h->census + 16 * EC0 : nullptr;
@@ -617,21 +620,21 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     int rc;
 #define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
     if (pool_fusable(h, d[0], need[EC1])) {
-        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0], nullptr, fsrc));
+        RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0], nullptr, fsrc, tb(DC2)));
     } else {
         RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), nullptr, nullptr, fsrc));
         RUN(launch_pool(h, buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
     }
     RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st, tb(EC2)));
     if (pool_fusable(h, d[1], need[EC3])) {
-        RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3), buf[B_P1]));
+        RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3), buf[B_P1], nullptr, nullptr, tb(DC5)));
     } else {
         RUN(launch_conv3(h, L[EC3], buf[B_E2], nullptr, buf[B_SYN1], d[1], need[EC3], n, st, tb(EC3)));
         RUN(launch_pool(h, buf[B_SYN1], buf[B_P1], d[1], L[EC3].cout, n, st));
     }
     RUN(launch_conv3(h, L[EC4], buf[B_P1], nullptr, buf[B_E4], d[2], need[EC4], n, st, tb(EC4)));
     if (pool_fusable(h, d[2], need[EC5])) {
-        RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5), buf[B_P2]));
+        RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5), buf[B_P2], nullptr, nullptr, tb(DC8)));
     } else {
         RUN(launch_conv3(h, L[EC5], buf[B_E4], nullptr, buf[B_SYN2], d[2], need[EC5], n, st, tb(EC5)));
         RUN(launch_pool(h, buf[B_SYN2], buf[B_P2], d[2], L[EC5].cout, n, st));
@@ -845,6 +848,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "b_lds")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: b_lds must be 0 or 1");
         h->b_lds = value;
+    } else if (!strcmp(name, "dead_stores")) {
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: dead_stores must be 0 or 1");
+        h->opt_dead_stores = value;
     } else if (!strcmp(name, "census")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: census must be 0 or 1");
         h->opt_census = value;

@@ -77,6 +77,12 @@ struct ConvArgs {
                                              // (tiles at the volume border need less: their kept centre is partly zeroed)
     float* pool_out;                         // optional: MaxPool3d(2) of the output, [tile][D/2][H/2][W/2][Cout] (main shape only)
     int* range_flag;                         // split-fp16 only: set to 1 if an activation is outside fp16's range (|x| > 65504)
+    // split-resident kernel: which part of its output some LATER layer reads -- [tile][6] rows of the consumer's output box, grown by
+    // store_grow (its 3x3x3 halo).  Copy-out stores outside it are skipped: a skip tensor is written in full by the encoder but read by
+    // the decoder only around the trimmed box (syn0 = ec1's output: dc2 reads 20 x 100 x 100 of 32 x 128 x 128 voxels, 38 %).  The fused
+    // max-pool output (pool_out) is not affected.  Null = store everything inside the tile's box.
+    const int* store_boxes = nullptr;
+    int store_grow = 0;
     unsigned* census = nullptr;              // split-resident kernels: 16 words of this layer's max |stored activation| (float bits, atomicMax;
                                              // see census_note).  Feeds the per-layer activation exponents and the low-range flag
     unsigned* first_census = nullptr;        // ... of the fused ec0 (instantiation FIRST)

@@ -625,6 +625,15 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     }
     static_assert(NREP == 2, "the operand list below names both halves");
     asm volatile("" : "+v"(scv[0]), "+v"(scv[1]), "+v"(shv[0]), "+v"(shv[1]));
+    // what the copy-out writes: the tile's box, cut down to what the consumer of this tensor reads (ConvArgs::store_boxes)
+    int clo[3], chi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { clo[i] = blo[i]; chi[i] = bhi[i]; }
+    if (a.store_boxes) {
+        const int* sb = a.store_boxes + 6 * tile;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { clo[i] = max(clo[i], sb[i] - a.store_grow); chi[i] = min(chi[i], sb[3 + i] + a.store_grow); }
+    }
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
@@ -709,7 +718,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 const int c = (it & 3) * 32, zc = it >> 2;
                 const int xc = kWide ? c % kTX : 0, yc = c / kTX;
                 const int oz = oz0 + zc, oy = oyl + yc, ox = oxl + xc;
-                if (cok && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1] && ox >= blo[2] && ox < bhi[2]) {
+                if (cok && oz >= clo[0] && oz < chi[0] && oy >= clo[1] && oy < chi[1] && ox >= clo[2] && ox < chi[2]) {
                     const unsigned uni = (unsigned)(((oz * a.H + oy0 + yc) * a.W + ox0 + xc) * 64);                // wave-uniform
                     float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
                     const float4 val = *reinterpret_cast<const float4*>(lds + (it * 256 + tid) * 16);
