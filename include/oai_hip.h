@@ -196,6 +196,10 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *   "xcd_group" n (32)  logical blocks dealt to one XCD at a time; 0 = plain launch order
  *   "fuse_first" 0|1 (1) ec0 (networks.py:43) computed inside ec1's halo staging instead of as its own launch (when ec1 is one main-shape launch)
  *   "b_lds" 0|1 (0)     conv weight fragments through a three-slot LDS ring shared by the four waves of a workgroup
+ *   "wide" 0|1|2 (1)    layers with Cout % 128 == 0 run conv3_igemm_sres2: one 8-wave workgroup per CU computes 128 couts of a
+ *                       block from ONE double-buffered halo box (unet_sres2.h); 1 = launches of >= 1024 workgroups, 2 = always
+ *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
+ *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)
  * Unknown names and out-of-range values return OAI_ERR_ARG. */
 int oai_unet_set_option(oai_unet* h, const char* name, int value);
 

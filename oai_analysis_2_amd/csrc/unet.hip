@@ -10,6 +10,7 @@
 #include "common.h"
 #include "unet_kernels.h"
 #include "unet_sres.h"
+#include "unet_sres2.h"
 
 namespace oai {
 
@@ -53,6 +54,7 @@ struct oai_unet {
     // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
     int act_exp[18] = {0};
     bool calibrated = false;
+    int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
@@ -393,6 +395,16 @@ template <int MREP, int KC, int RX, int RY, int WY, int WX>
 static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {   // a.boxes set by the caller
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
     if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
+    // conv3_igemm_sres2 (unet_sres2.h): main shape of the default split-resident configuration, 128 couts per workgroup
+    // ... when the launch is at least four rounds of its one-workgroup-per-CU blocks (ec6 of the reference network: 2.5 rounds, 13 % slower
+    // than as twice as many 4-wave workgroups)
+    bool wide = KC == 8 && RX == 16 && RY == 2 && WY == 4 && WX == 1 && h->sres && h->opt_wide && h->sres_mrep == 4 && !h->sres_ring &&
+                !h->b_lds && !a.first_w && !a.head_w && a.Cout % 128 == 0;
+    if (wide && h->opt_wide == 1) {
+        const size_t nwg = (size_t)ntiles * cdiv(box.hi[0] - box.lo[0], 4) * cdiv(box.hi[1] - box.lo[1], WY * RY) * cdiv(box.hi[2] - box.lo[2], WX * RX) * (a.Cout / 128);
+        wide = nwg >= 1024;
+    }
+    if (wide) a.ncb = a.Cout / 128;
     const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split kernels use 2 z slices per block (4: split-resident)
     a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? h->sres_mrep : 2) : MREP);
     a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
@@ -422,6 +434,27 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
             if (a.first_w) {                                         // ec0 fused into ec1's halo staging (first_fusable guarantees mrep 4, no strips)
                 conv3_igemm_sres<4, RX, RY, WY, WX, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+                done = true;
+            }
+        }
+        if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
+            if (wide) {
+                static const int var = diag_env("OAI_WIDE_VAR", 0);         // -DOAI_DIAG builds only; constant 0 otherwise
+#ifdef OAI_DIAG
+                if (var == 1) conv3_igemm_sres2<RX, RY, WY, WX, 1><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 2) conv3_igemm_sres2<RX, RY, WY, WX, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 3) conv3_igemm_sres2<RX, RY, WY, WX, 3><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 4) conv3_igemm_sres2<RX, RY, WY, WX, 4><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 5) conv3_igemm_sres2<RX, RY, WY, WX, 5><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 6) conv3_igemm_sres2<RX, RY, WY, WX, 6><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 7) conv3_igemm_sres2<RX, RY, WY, WX, 7><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 8) conv3_igemm_sres2<RX, RY, WY, WX, 8><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 9) conv3_igemm_sres2<RX, RY, WY, WX, 9><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else if (var == 10) conv3_igemm_sres2<RX, RY, WY, WX, 10><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                else
+#endif
+                conv3_igemm_sres2<RX, RY, WY, WX, 0><<<grid, 512, 0, st>>>(a, h->zero_rec);
+                (void)var;
                 done = true;
             }
         }
@@ -848,6 +881,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "b_lds")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: b_lds must be 0 or 1");
         h->b_lds = value;
+    } else if (!strcmp(name, "wide")) {
+        OAI_CHECK_ARG(value >= 0 && value <= 2, "oai_unet_set_option: wide must be 0, 1 or 2 (2 = also for launches of fewer than 1024 workgroups)");
+        h->opt_wide = value;
     } else if (!strcmp(name, "dead_stores")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: dead_stores must be 0 or 1");
         h->opt_dead_stores = value;

@@ -16,7 +16,7 @@ dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 layers, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
-    main = "conv3_igemm_sres<4, 16, 2, 4, 1" in n
+    main = "conv3_igemm_sres<4, 16, 2, 4, 1" in n or "conv3_igemm_sres2<16, 2, 4, 1" in n
     if "conv3_first" in n: layers.append(["ec0", dur(r), 1]); continue
     if "upconv2" in n or main: layers.append([None, dur(r), 1]); cur = layers[-1]; continue
     if "conv3_igemm_sres" in n and cur is not None: cur[1] += dur(r); cur[2] += 1; continue      # strip launches belong to the layer before them

@@ -8,6 +8,8 @@ from oai_analysis_2_amd.segmentation.engine import UNetEngine
 prec = os.environ.get("PREC", "fp16x3")
 eng = UNetEngine(make_unet_state_dict(0), precision=prec)
 vol = torch.from_numpy(make_volume(0)).cuda()
+for kv in os.environ.get("OPTIONS", "").split(","):          # e.g. OPTIONS=wide=0,dead_stores=0
+    if kv: eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for rep in range(int(os.environ.get("REPS", "3"))):
     torch.cuda.synchronize(); t = time.time()
     eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), None, 0, 160, (8, 16, 16))
