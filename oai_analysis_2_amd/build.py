@@ -58,9 +58,14 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), lib
         if force or _stale(obj, [src] + headers):
             jobs.append((src, obj))
 
+    # diagnostic builds only: OAI_PACKED_TU=warp.hip compiles the named sources WITH packed fp32 ops (hipcc's default), to re-measure
+    # the hazard of profiles/r02_packed_fp32_hazard.md against the current kernels (scripts/stress_overlap.py)
+    packed_tu = set(filter(None, os.environ.get("OAI_PACKED_TU", "").split(","))) if "-DOAI_DIAG" in extra_flags else set()
+
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, *extra_flags, "-x", "hip", "-c", src, "-o", obj]
+        flags = [f for f in FLAGS if f not in ("-Xclang", "-target-feature", "-packed-fp32-ops")] if os.path.basename(src) in packed_tu else FLAGS
+        cmd = [hipcc, *flags, *extra_flags, "-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -82,7 +87,32 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), lib
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
             print(f"[oai build] linked {LIB}", file=sys.stderr)
+        if not packed_tu:
+            check_no_packed_fp32(LIB)
     return LIB
+
+
+def check_no_packed_fp32(lib: str) -> None:
+    """The build FAILS if any gfx950 code object of the library contains a packed fp32 VALU instruction: a future float2
+    expression, an inline-asm v_pk op or a toolchain change would otherwise bring the hazard of profiles/r03_packed_fp32_hazard.md back
+    silently (a packed op that reads src1 across halves returns a zero product in lanes 48..63 beside 16-bit MFMAs)."""
+    import glob
+    import re
+    import tempfile
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        print("[oai build] WARNING: no llvm-objdump: the packed-fp32 guard did not run", file=sys.stderr)
+        return
+    with tempfile.TemporaryDirectory() as work:
+        shutil.copy(lib, os.path.join(work, "lib.so"))
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+        n = 0
+        for o in glob.glob(os.path.join(work, "lib.so.*gfx950*")):
+            text = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+            n += len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", text))
+    if n:
+        os.remove(lib)
+        raise RuntimeError(f"{n} packed fp32 VALU instruction(s) in {lib}: refusing to ship it (see profiles/r03_packed_fp32_hazard.md)")
 
 
 DIAG_LIB = os.path.join(os.path.dirname(HERE), "build", "diag", "liboai_hip_diag.so")

@@ -98,3 +98,21 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
         for i0, i1 in zip(mf, mf[1:]):                                   # inside a tap stream (MFMAs a few lines apart; the four ML variants lie far apart)
             if i1 - i0 <= 60:
                 assert not [ln for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside the tap stream"
+    # (d) conv3_igemm_sres2 counts vmcnt by hand (unet_sres2.h): between the first and the last MFMA of a tap stream there must be no vector-memory
+    # operation the compiler added on its own (a scratch reload is a load: it shifts every counted wait) and no wait other than the counted ones
+    sym = "_ZN3oai17conv3_igemm_sres2ILi16ELi2ELi4ELi1ELi0EEEvNS_8ConvArgsEPKh"
+    m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
+    assert m, f"{sym} not in the library"
+    body = m.group(1).split("\n")
+    mf = [i for i, ln in enumerate(body) if "v_mfma_f32_32x32x16_f16" in ln]
+    assert len(mf) >= 1600                                               # 27 taps x 24 MFMAs for ML = 4, 18 / 12 / 6 for the trimmed variants
+    streams, start = [], mf[0]
+    for i0, i1 in zip(mf, mf[1:] + [10 ** 9]):
+        if i1 - i0 > 120:                                               # a gap: chunk-loop boundary or the next ML variant
+            streams.append((start, i0)); start = i1
+    assert len(streams) >= 4
+    for s0, s1 in streams:
+        seg = body[s0:s1]
+        assert not [ln for ln in seg if "scratch_" in ln], "scratch traffic inside conv3_igemm_sres2's tap stream"
+        loads = [ln for ln in seg if "global_load_dwordx4" in ln or "global_load_lds_dwordx4" in ln]
+        assert all("s[" in ln.split("//")[0] or "lds" in ln for ln in loads), "a weight-fragment load that is not the SGPR-base asm form"
