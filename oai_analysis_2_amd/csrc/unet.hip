@@ -398,11 +398,14 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
     // conv3_igemm_sres2 (unet_sres2.h): main shape of the default split-resident configuration, 128 couts per workgroup
     // ... when the launch is at least four rounds of its one-workgroup-per-CU blocks (ec6 of the reference network: 2.5 rounds, 13 % slower
     // than as twice as many 4-wave workgroups)
-    bool wide = KC == 8 && RX == 16 && RY == 2 && WY == 4 && WX == 1 && h->sres && h->opt_wide && h->sres_mrep == 4 && !h->sres_ring &&
+    constexpr bool kMainShape = RX == 16 && RY == 2 && WY == 4 && WX == 1;
+    // + the 4-row y strip (dc5: 2.27 -> 1.89 ms); the 4-column x strip <4,8,4,1> measured slower there (2.05 -> 2.30 ms) and stays on the 4-wave kernel
+    constexpr bool kWideShape = kMainShape || (RX == 16 && RY == 2 && WY == 2 && WX == 2);
+    bool wide = KC == 8 && kWideShape && h->sres && h->opt_wide && h->sres_mrep == 4 && !h->sres_ring &&
                 !h->b_lds && !a.first_w && !a.head_w && a.Cout % 128 == 0;
     if (wide && h->opt_wide == 1) {
         const size_t nwg = (size_t)ntiles * cdiv(box.hi[0] - box.lo[0], 4) * cdiv(box.hi[1] - box.lo[1], WY * RY) * cdiv(box.hi[2] - box.lo[2], WX * RX) * (a.Cout / 128);
-        wide = nwg >= 1024;
+        wide = nwg >= (kMainShape ? 1024 : 512);
     }
     if (wide) a.ncb = a.Cout / 128;
     const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split kernels use 2 z slices per block (4: split-resident)
@@ -437,7 +440,7 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
                 done = true;
             }
         }
-        if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
+        if constexpr (kWideShape) {
             if (wide) {
                 static const int var = diag_env("OAI_WIDE_VAR", 0);         // -DOAI_DIAG builds only; constant 0 otherwise
 #ifdef OAI_DIAG

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(512, 1) conv3_igemm_sres2(const ConvArgs a, co
     constexpr int PIECES = HVOX * 4;                             // 16-byte slots of the halo box
     constexpr int NIT = (PIECES + 511) / 512;                    // LDS-DMA instructions per thread per chunk (9 for 6 x 10 x 18)
     constexpr int BUF = NIT * 512 * 16;                          // bytes of one halo buffer (whole 1-KiB wave writes)
-    static_assert(NIT <= 9, "one piece per tap in taps 0..NIT-1; the counted waits below assume NIT <= 9 < 27");
+    static_assert(NIT <= 10 && 2 * BUF <= 160 * 1024, "one piece per tap in taps 0..NIT-1 (< 27); two halo buffers must fit the CU's LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
