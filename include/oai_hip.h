@@ -198,6 +198,8 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *   "b_lds" 0|1 (0)     conv weight fragments through a three-slot LDS ring shared by the four waves of a workgroup
  *   "wide" 0|1|2 (1)    layers with Cout % 128 == 0 run conv3_igemm_sres2: one 8-wave workgroup per CU computes 128 couts of a
  *                       block from ONE double-buffered halo box (unet_sres2.h); 1 = launches of >= 1024 workgroups, 2 = always
+ *   "shared_enc" 0|1 (1) oai_segment_tiles computes ec0 -> ec1 once over the padded volume + a 2-voxel shell per tile (needs the workspace
+ *                       of oai_segment_workspace_bytes; geometries it does not fit fall back to per-tile computation)
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)
  * Unknown names and out-of-range values return OAI_ERR_ARG. */
@@ -205,6 +207,11 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value);
 
 /* Bytes of device scratch oai_unet_forward_* needs for `batch` tiles of (td,th,tw). */
 size_t oai_unet_workspace_bytes(const oai_unet* h, int td, int th, int tw, int batch);
+/* ... and what oai_segment_tiles would like for a (D,H,W) volume: the same plus the max-pooled ec1 over the reflect-padded volume (1 GB at
+ * 384x384x160) when the geometry allows the shared encoder pass -- ec0 -> ec1 (networks.py:109-113) computed once per volume instead of once
+ * per overlapping tile (image_transforms.py:407-434: tiles overlap 2 x 1.33 x 1.33), bit-identical maps.  With only
+ * oai_unet_workspace_bytes the call computes every tile on its own. */
+size_t oai_segment_workspace_bytes(const oai_unet* h, int D, int H, int W, const int tile_zyx[3], const int overlap_zyx[3], int batch);
 
 /* B3 seam: logits[B][n_classes][td][th][tw] = UNet(tiles[B][1][td][th][tw]) (NCDHW like
  * networks.py:109-149), zero conv padding at the tile border, no trimming. */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "oai_unet_set_act_exponents": (_I, [_P, C.POINTER(_I)]),
     "oai_unet_set_option": (_I, [_P, C.c_char_p, _I]),
     "oai_unet_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
+    "oai_segment_workspace_bytes": (_Z, [_P, _I, _I, _I, _I3, _I3, _I]),
     "oai_unet_forward_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "oai_unet_volume_flops": (_D, [_P, _I, _I, _I, _I3, _I3, _I3, _I, _I]),

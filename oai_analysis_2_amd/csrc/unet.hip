@@ -54,6 +54,7 @@ struct oai_unet {
     // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
     int act_exp[18] = {0};
     bool calibrated = false;
+    int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
@@ -392,16 +393,17 @@ static Plan plan_workspace(const oai_unet* h, int td, int th, int tw, int batch)
 }
 
 template <int MREP, int KC, int RX, int RY, int WY, int WX>
-static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {   // a.boxes set by the caller
+static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int ntiles, hipStream_t st, int mrep_override = 0) {   // a.boxes set by the caller
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
     if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
     // conv3_igemm_sres2 (unet_sres2.h): main shape of the default split-resident configuration, 128 couts per workgroup
     // ... when the launch is at least four rounds of its one-workgroup-per-CU blocks (ec6 of the reference network: 2.5 rounds, 13 % slower
     // than as twice as many 4-wave workgroups)
+    const int sres_mrep = mrep_override ? mrep_override : h->sres_mrep;       // z slices per block of the split-resident kernel for THIS launch
     constexpr bool kMainShape = RX == 16 && RY == 2 && WY == 4 && WX == 1;
     // + the 4-row y strip (dc5: 2.27 -> 1.89 ms); the 4-column x strip <4,8,4,1> measured slower there (2.05 -> 2.30 ms) and stays on the 4-wave kernel
     constexpr bool kWideShape = kMainShape || (RX == 16 && RY == 2 && WY == 2 && WX == 2);
-    bool wide = KC == 8 && kWideShape && h->sres && h->opt_wide && h->sres_mrep == 4 && !h->sres_ring &&
+    bool wide = KC == 8 && kWideShape && h->sres && h->opt_wide && sres_mrep == 4 && !h->sres_ring &&
                 !h->b_lds && !a.first_w && !a.head_w && a.Cout % 128 == 0;
     if (wide && h->opt_wide == 1) {
         const size_t nwg = (size_t)ntiles * cdiv(box.hi[0] - box.lo[0], 4) * cdiv(box.hi[1] - box.lo[1], WY * RY) * cdiv(box.hi[2] - box.lo[2], WX * RX) * (a.Cout / 128);
@@ -409,7 +411,7 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
     }
     if (wide) a.ncb = a.Cout / 128;
     const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split kernels use 2 z slices per block (4: split-resident)
-    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? h->sres_mrep : 2) : MREP);
+    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? sres_mrep : 2) : MREP);
     a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
     a.nbx = cdiv(box.hi[2] - box.lo[2], WX * RX);
     unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
@@ -463,9 +465,9 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         }
         if (done) { }
         else if (a.first_w) return set_error(OAI_ERR_ARG, "fused ec0 asked of a tile shape that has no such kernel");
-        else if (h->sres_mrep == 4 && h->b_lds) conv3_igemm_sres<4, RX, RY, WY, WX, false, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
-        else if (h->sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
-        else if (h->sres_ring) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+        else if (sres_mrep == 4 && h->b_lds) conv3_igemm_sres<4, RX, RY, WY, WX, false, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+        else if (sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
+        else if (h->sres_ring && !mrep_override) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else conv3_igemm_sres<2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a, h->zero_rec);
     }
     else if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
@@ -502,16 +504,22 @@ static bool first_fusable(const oai_unet* h, const Box& ec1_box) {
     return hr == 0 && wr == 0;
 }
 
-static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
-                        const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
-                        float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr,
-                        const int* store_boxes = nullptr) {
-    ConvArgs a;
+// shared encoder pass: where the copy-out of the volume-wide ec1 scatters its voxels (ConvArgs::sc_*)
+struct Scatter { const int* boxes; int ntiles, tile0; int g[3], e[3], t[3]; };
+
+// everything of ConvArgs that does not depend on the tile shape
+static int fill_conv_args(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out, const int dims[3],
+                          const int* boxes, float* pool_out, const ConvArgs* head, const TileSource* first, const int* store_boxes,
+                          const Scatter* sc, ConvArgs& a) {
     if (head) a = *head;                   // the fused dc0 fields (see ConvArgs); everything else is set below
     if (store_boxes && h->sres && h->opt_dead_stores) { a.store_boxes = store_boxes; a.store_grow = 1; }
     if (first) {                           // ec0 fused into this layer's staging (first_fusable)
         a.first_w = h->L[EC0].plain; a.first_scale = h->L[EC0].scale_f16; a.first_shift = h->L[EC0].shift_f16; a.first_src = *first;   // (sres => fp16x3)
         a.first_census = h->opt_census ? h->census + 16 * EC0 : nullptr;
+    }
+    if (sc) {
+        a.sc_boxes = sc->boxes; a.sc_ntiles = sc->ntiles; a.sc_tile0 = sc->tile0;
+        for (int i = 0; i < 3; ++i) { a.sc_g[i] = sc->g[i]; a.sc_e[i] = sc->e[i]; a.sc_t[i] = sc->t[i]; }
     }
     a.boxes = boxes;
     a.pool_out = pool_out;
@@ -531,6 +539,27 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     a.relu = 1;
     if (h->sres && (size_t)dims[0] * dims[1] * dims[2] * 128 >= (1ull << 32))      // staging plan and copy-out hold 32-bit byte offsets inside one / two chunk planes
         return set_error(OAI_ERR_ARG, "tile level %dx%dx%d too large for the split-resident kernel (>= 2^25 voxels)", dims[0], dims[1], dims[2]);
+    return OAI_OK;
+}
+
+// one launch of ONE given tile shape over `box` (the faces of the per-tile shell pass, where launch_conv3's main + strips cover does not fit)
+// `pool_only` (main shape): the max-pooled tensor is all this launch leaves behind -- fused pool into pool_only, 2 z slices per block (both
+// slices of a block are then inside the 2-voxel face), the copy-out of the layer's own output suppressed through an empty store box
+template <int RX, int RY, int WY, int WX>
+static int launch_conv3_one(const oai_unet* h, const Layer& L, const float* s0, float* out, const int dims[3], const Box& box, int ntiles,
+                            hipStream_t st, const int* boxes, float* pool_only = nullptr) {
+    ConvArgs a;
+    if (int rc = fill_conv_args(h, L, s0, nullptr, out, dims, boxes, pool_only, nullptr, nullptr, nullptr, nullptr, a)) return rc;
+    if (pool_only) { a.store_boxes = boxes; a.store_grow = -(1 << 20); }          // consumer box "grown" by -2^20: nothing of the output tensor is written
+    return launch_conv3_shape<4, 8, RX, RY, WY, WX>(h, a, box, ntiles, st, pool_only ? 2 : 0);
+}
+
+static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
+                        const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
+                        float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr,
+                        const int* store_boxes = nullptr, const Scatter* sc = nullptr) {
+    ConvArgs a;
+    if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
     int ny, nx, hr, wr;
     strip_plan(h, box, ny, nx, hr, wr);
@@ -601,14 +630,16 @@ static bool pool_fusable(const oai_unet* h, const int dims[3], const Box& box) {
     return dims[0] % 4 == 0 && dims[1] % 8 == 0 && dims[2] % 16 == 0;
 }
 
-static int launch_pool(const oai_unet* h, const float* in, float* out, const int dims[3], int C, int ntiles, hipStream_t st) {
+static int launch_pool(const oai_unet* h, const float* in, float* out, const int dims[3], int C, int ntiles, hipStream_t st, int shell_only = 0) {
     if (h->sres) {
         const int nch = (C + 15) / 16;
-        const size_t total = (size_t)ntiles * (dims[0] / 2) * (dims[1] / 2) * (dims[2] / 2) * nch * 4;
+        const size_t Do = dims[0] / 2, Ho = dims[1] / 2, Wo = dims[2] / 2;
+        const size_t faces = Do * Ho * Wo - (Do - 2) * (Ho - 2) * (Wo - 2) - (shell_only == 2 ? 2 * Ho * Wo : 0);
+        const size_t total = (size_t)ntiles * (shell_only ? faces : Do * Ho * Wo) * nch * 4;
         size_t blocks = (total + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;
         maxpool2_sres_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const unsigned char*>(in), reinterpret_cast<unsigned char*>(out),
-                                                                dims[0], dims[1], dims[2], nch, total);
+                                                                dims[0], dims[1], dims[2], nch, total, shell_only);
         OAI_CHECK_LAUNCH();
         return OAI_OK;
     }
@@ -620,12 +651,27 @@ static int launch_pool(const oai_unet* h, const float* in, float* out, const int
     return OAI_OK;
 }
 
+// Shared encoder pass.  Tiles overlap 2 x in z and 1.33 x in y and x, so ec0 / ec1 evaluate every input voxel ~3.6 x.  An ec1
+// output at least 2 voxels from its tile's faces sees no zero padding (ec0 differs from the volume-wide convolution at distance 0, ec1 at
+// distances 0 and 1) and -- every launch accumulates in the same k order -- is BIT-IDENTICAL in every tile that contains it.  So ec0 -> ec1
+// (+ the fused max-pool) run ONCE per batch over the part of the reflect-padded volume its tiles cover, as one big "tile": the pooled tensor
+// goes to SP0 (volume strides), and the copy-out of ec1 itself scatters every voxel straight into the per-tile syn0 tensors of the tiles
+// whose dc2 reads it (the skip read [need - 1, need + 1) lies inside the interior).  Per tile only the 2-voxel shell of ec1 is recomputed
+// (ec0 on a 3-voxel shell, six thin face launches, the pooled faces) and the interior of the tile's pooled tensor is copied out of SP0.
+// ec1 is 22 ms of a 169 ms volume at 0.167 of the MFMA peak; the shared pass takes 8.7 ms.
+struct SharedEnc {
+    float* SP0;                         // [cout / 16 chunks][PD / 2][PH / 2][PW / 2]: the max-pooled ec1 of the padded volume
+    int PD, PH, PW;                     // reflect-padded volume = eff * grid + 2 * overlap
+    const float* vol; int D, H, W;      // the volume itself (the pass gathers it with Partition's reflect padding)
+    int grid[3], eff[3], overlap[3];
+};
+
 // One batch of `n` tiles through the whole network; kept-centre blocks go to blocks_out.
 // `table` (device, may be null) = per-tile boxes [layer][table_tiles][6] of the whole call; this batch starts at tile
 // `t0` of it.  For up-convs the table row holds the INPUT box (the halved output box).
 static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[18], int out_mode,
                      float* blocks_out, char* ws, const Plan& plan, hipStream_t st,
-                     const int* table = nullptr, int table_tiles = 0, int t0 = 0) {
+                     const int* table = nullptr, int table_tiles = 0, int t0 = 0, const SharedEnc* se = nullptr) {
     auto tb = [&](int layer) -> const int* { return table ? table + ((size_t)layer * table_tiles + t0) * 6 : nullptr; };
     const Layer* L = h->L;
     float* buf[B_COUNT];
@@ -634,6 +680,55 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     for (int l = 0; l < 4; ++l) { d[l][0] = src.td >> l; d[l][1] = src.th >> l; d[l][2] = src.tw >> l; }
     const size_t v0 = (size_t)src.td * src.th * src.tw;
 
+    int rc;
+#define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
+    if (se) {
+        // ---- ec0 -> ec1 once over the z range of the padded volume that this batch's tiles cover
+        {
+            TileSource vs{};                                        // the padded volume as ONE tile: reflect_index(c - overlap) is Partition's padding
+            vs.vol = se->vol; vs.D = se->D; vs.H = se->H; vs.W = se->W; vs.td = se->PD; vs.th = se->PH; vs.tw = se->PW;
+            vs.ez = se->PD; vs.ey = se->PH; vs.ex = se->PW; vs.oz = se->overlap[0]; vs.oy = se->overlap[1]; vs.ox = se->overlap[2]; vs.gy = 1; vs.gx = 1;
+            const int per_row = se->grid[1] * se->grid[2], P[3] = {se->PD, se->PH, se->PW};
+            Box bx;
+            bx.lo[0] = se->eff[0] * (src.tile_begin / per_row); bx.hi[0] = se->eff[0] * ((src.tile_begin + n - 1) / per_row) + src.td;
+            bx.lo[1] = 0; bx.hi[1] = P[1]; bx.lo[2] = 0; bx.hi[2] = P[2];
+            Scatter sc;
+            sc.boxes = tb(DC2); sc.ntiles = n; sc.tile0 = src.tile_begin;
+            for (int i = 0; i < 3; ++i) { sc.g[i] = se->grid[i]; sc.e[i] = se->eff[i]; }
+            sc.t[0] = src.td; sc.t[1] = src.th; sc.t[2] = src.tw;
+            RUN(launch_conv3(h, L[EC1], nullptr, nullptr, buf[B_SYN0], P, bx, 1, st, nullptr, se->SP0, nullptr, &vs, nullptr, &sc));
+        }
+        // ---- the interior of this batch's pooled tensors is a copy, their faces are computed
+        const int nch1 = (L[EC1].cout + 15) / 16;
+        {
+            const size_t total = (size_t)n * (d[1][0] * d[1][1] * d[1][2]) * nch1 * 4;
+            size_t blocks = (total + 255) / 256;
+            if (blocks > 256 * 64) blocks = 256 * 64;
+            pooled_gather_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const unsigned char*>(se->SP0), reinterpret_cast<unsigned char*>(buf[B_P0]), src,
+                                                                   d[1][0], d[1][1], d[1][2], se->PD / 2, se->PH / 2, se->PW / 2, nch1, total);
+            OAI_CHECK_LAUNCH();
+        }
+        {   // ec0 where ec1's shell reads it: closer than 3 voxels to a face (voxel pairs along x, enumerated slab by slab)
+            const size_t pairs = (size_t)6 * d[0][1] * (d[0][2] / 2) + (size_t)(d[0][0] - 6) * 6 * (d[0][2] / 2) + (size_t)(d[0][0] - 6) * (d[0][1] - 6) * 4;
+            dim3 grid(cdiv(pairs, 256), n);
+            conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale_f16, L[EC0].shift_f16, reinterpret_cast<unsigned char*>(buf[B_E0]), 1,
+                                                              h->range_flag, h->opt_census ? h->census + 16 * EC0 : nullptr, 3);
+            OAI_CHECK_LAUNCH();
+        }
+        const int td = d[0][0], th = d[0][1], tw = d[0][2];
+        const Box zlo = {{0, 0, 0}, {2, th, tw}}, zhi = {{td - 2, 0, 0}, {td, th, tw}};                      // the six faces, 2 voxels thick, disjoint
+        const Box ylo = {{2, 0, 0}, {td - 2, 2, tw}}, yhi = {{2, th - 2, 0}, {td - 2, th, tw}};
+        const Box xlo = {{2, 2, 0}, {td - 2, th - 2, 2}}, xhi = {{2, 2, tw - 2}, {td - 2, th - 2, tw}};
+        // z faces: main shape with 2 slices per block; nobody reads their part of the per-tile syn0, only its max-pool (fused into the launch)
+        const bool zpool = tb(EC1) != nullptr && h->opt_dead_stores;
+        RUN((launch_conv3_one<16, 2, 4, 1>(h, L[EC1], buf[B_E0], buf[B_SYN0], d[0], zlo, n, st, tb(EC1), zpool ? buf[B_P0] : nullptr)));
+        RUN((launch_conv3_one<16, 2, 4, 1>(h, L[EC1], buf[B_E0], buf[B_SYN0], d[0], zhi, n, st, tb(EC1), zpool ? buf[B_P0] : nullptr)));
+        RUN((launch_conv3_one<16, 2, 1, 4>(h, L[EC1], buf[B_E0], buf[B_SYN0], d[0], ylo, n, st, tb(EC1))));   // y faces: blocks of 4 x 2 x 64
+        RUN((launch_conv3_one<16, 2, 1, 4>(h, L[EC1], buf[B_E0], buf[B_SYN0], d[0], yhi, n, st, tb(EC1))));
+        RUN((launch_conv3_one<2, 16, 4, 1>(h, L[EC1], buf[B_E0], buf[B_SYN0], d[0], xlo, n, st, tb(EC1))));   // x faces: blocks of 4 x 64 x 2
+        RUN((launch_conv3_one<2, 16, 4, 1>(h, L[EC1], buf[B_E0], buf[B_SYN0], d[0], xhi, n, st, tb(EC1))));
+        RUN(launch_pool(h, buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st, zpool ? 2 : 1));               // the (other) pooled faces: windows inside the shell
+    } else {
     const bool fuse_first = first_fusable(h, need[EC1]);
     const TileSource* fsrc = fuse_first ? &src : nullptr;
     if (!fuse_first) {   // ec0 (+ gather)
@@ -644,22 +739,21 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
         const float* sc0 = f16 ? L[EC0].scale_f16 : L[EC0].scale;
         const float* sh0 = f16 ? L[EC0].shift_f16 : L[EC0].shift;
         unsigned* cen0 = h->opt_census ? h->census + 16 * EC0 : nullptr;
-        if (h->sres && c == 32) conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0);
-        else if (h->sres && c == 16) conv3_first_sres_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0);
-        else if (h->sres && c == 8) conv3_first_sres_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0);
+        if (h->sres && c == 32) conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0, 0);
+        else if (h->sres && c == 16) conv3_first_sres_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0, 0);
+        else if (h->sres && c == 8) conv3_first_sres_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0, 0);
         else if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
         else if (c == 16) conv3_first_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
         else if (c == 8) conv3_first_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
         else return set_error(OAI_ERR_ARG, "ec0 cout %d unsupported (8, 16 or 32)", c);
         OAI_CHECK_LAUNCH();
     }
-    int rc;
-#define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
     if (pool_fusable(h, d[0], need[EC1])) {
         RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), buf[B_P0], nullptr, fsrc, tb(DC2)));
     } else {
         RUN(launch_conv3(h, L[EC1], buf[B_E0], nullptr, buf[B_SYN0], d[0], need[EC1], n, st, tb(EC1), nullptr, nullptr, fsrc));
         RUN(launch_pool(h, buf[B_SYN0], buf[B_P0], d[0], L[EC1].cout, n, st));
+    }
     }
     RUN(launch_conv3(h, L[EC2], buf[B_P0], nullptr, buf[B_E2], d[1], need[EC2], n, st, tb(EC2)));
     if (pool_fusable(h, d[1], need[EC3])) {
@@ -884,6 +978,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "b_lds")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: b_lds must be 0 or 1");
         h->b_lds = value;
+    } else if (!strcmp(name, "shared_enc")) {
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: shared_enc must be 0 or 1");
+        h->opt_shared = value;
     } else if (!strcmp(name, "wide")) {
         OAI_CHECK_ARG(value >= 0 && value <= 2, "oai_unet_set_option: wide must be 0, 1 or 2 (2 = also for launches of fewer than 1024 workgroups)");
         h->opt_wide = value;
@@ -1153,6 +1250,31 @@ static SegParams seg_params(int D, int H, int W, const int tile[3], const int ov
     return p;
 }
 
+// bytes of the two volume-wide tensors of the shared encoder pass, or 0 when its conditions do not hold for this geometry
+static size_t shared_enc_bytes(const oai_unet* h, const int tile[3], const int overlap[3], const SegGeom& g, int P[3]) {
+    if (!h->sres || !h->opt_shared || !h->fuse_first || h->variant != 0 || h->sres_mrep != 4 || h->sres_ring || h->b_lds) return 0;
+    if (h->L[EC0].cout != 32 || h->L[EC1].c0 != 32 || h->L[EC1].cout % 16 != 0) return 0;
+    const int blk[3] = {4, 8, 16};                                         // the main block shape must tile the padded volume and the tile exactly
+    for (int i = 0; i < 3; ++i) {
+        P[i] = g.eff[i] * g.grid[i] + 2 * overlap[i];
+        // tile origins (multiples of eff) on block boundaries: a block of the pass lies inside or outside a tile, never across its start (scatter
+        // copy-out), and pooling windows are aligned; overlap >= 4: dc2's skip read stays >= 2 voxels inside the tile
+        if (tile[i] % blk[i] || P[i] % blk[i] || g.eff[i] % blk[i] || overlap[i] < 4 || tile[i] < 8) return 0;
+    }
+    const size_t pv = (size_t)P[0] * P[1] * P[2];
+    if (pv * 128 >= (1ull << 32)) return 0;                                // 32-bit piece offsets inside the pass's own planes
+    const size_t nch = (size_t)h->L[EC1].cout / 16;
+    return (nch * (pv / 8) * 64 + 255) / 256 * 256;
+}
+
+size_t oai_segment_workspace_bytes(const oai_unet* h, int D, int H, int W, const int tile[3], const int overlap[3], int batch) {
+    if (!h || !tile || !overlap || batch <= 0) return 0;
+    SegGeom g;
+    if (seg_geometry(D, H, W, tile, overlap, g)) return 0;
+    int P[3];
+    return plan_workspace(h, tile[0], tile[1], tile[2], batch).total + shared_enc_bytes(h, tile, overlap, g, P);
+}
+
 int oai_segment_tiles(oai_unet* h, const float* vol, int D, int H, int W, const int tile[3], const int overlap[3],
                       const int crop[3], int tile_begin, int tile_end, int out_mode, float* blocks, int batch,
                       void* ws, size_t ws_bytes, void* stream) {
@@ -1181,6 +1303,20 @@ int oai_segment_tiles(oai_unet* h, const float* vol, int D, int H, int W, const 
     int* table_dev = reinterpret_cast<int*>(ws);
     const SegParams sp = seg_params(D, H, W, tile, overlap, crop, g, trimmed);
     Box need[18];
+    // ---- shared encoder pass (run_batch: once per batch over the z range its tiles cover), when the geometry and the workspace allow it
+    SharedEnc se{};
+    bool shared = false;
+    if (trimmed && tile_end > tile_begin) {
+        int P[3];
+        const size_t sb = shared_enc_bytes(h, tile, overlap, g, P);
+        if (sb && plan.total + sb <= ws_bytes) {
+            shared = true;
+            se.SP0 = reinterpret_cast<float*>((char*)ws + plan.total);
+            se.PD = P[0]; se.PH = P[1]; se.PW = P[2];
+            se.vol = vol; se.D = D; se.H = H; se.W = W;
+            for (int i = 0; i < 3; ++i) { se.grid[i] = g.grid[i]; se.eff[i] = g.eff[i]; se.overlap[i] = overlap[i]; }
+        }
+    }
     for (int c0 = tile_begin; c0 < tile_end; c0 += kMaxTilesPerTable) {
         const int nc = tile_end - c0 < kMaxTilesPerTable ? tile_end - c0 : kMaxTilesPerTable;
         box_table_kernel<<<cdiv(nc, 64), 64, 0, st>>>(sp, c0, nc, table_dev);
@@ -1203,7 +1339,7 @@ int oai_segment_tiles(oai_unet* h, const float* vol, int D, int H, int W, const 
             if (uni[0].hi[0] == 0) continue;                 // every tile of the batch is dead
             src.tile_begin = t;
             if (int rc = run_batch(h, src, n, uni, out_mode, blocks + (size_t)(t - tile_begin) * h->n_classes * bvox,
-                                   (char*)ws, plan, st, table_dev, nc, t - c0)) return rc;
+                                   (char*)ws, plan, st, table_dev, nc, t - c0, shared ? &se : nullptr)) return rc;
         }
     }
     return OAI_OK;

@@ -83,6 +83,13 @@ struct ConvArgs {
     // max-pool output (pool_out) is not affected.  Null = store everything inside the tile's box.
     const int* store_boxes = nullptr;
     int store_grow = 0;
+    // split-resident kernel, instantiation FIRST, shared encoder pass (the "tile" is the whole reflect-padded volume): instead of ONE output
+    // tensor the copy-out SCATTERS every voxel into the per-tile tensors out[t] of the tiles t in [sc_tile0, sc_tile0 + sc_ntiles) whose
+    // consumer reads it: tile (iz, iy, ix) of the sc_g grid starts at (iz, iy, ix) * sc_e and is sc_t large; sc_boxes[t - sc_tile0] = the
+    // consumer's (dc2's) output box in tile coordinates, read with a 1-voxel halo.  Null = the ordinary copy-out.
+    const int* sc_boxes = nullptr;
+    int sc_ntiles = 0, sc_tile0 = 0;
+    int sc_g[3] = {0, 0, 0}, sc_e[3] = {0, 0, 0}, sc_t[3] = {0, 0, 0};
     unsigned* census = nullptr;              // split-resident kernels: 16 words of this layer's max |stored activation| (float bits, atomicMax;
                                              // see census_note).  Feeds the per-layer activation exponents and the low-range flag
     unsigned* first_census = nullptr;        // ... of the fused ec0 (instantiation FIRST)

@@ -697,6 +697,44 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         }
                     }
             }
+        } else if (FIRST && a.sc_boxes) {
+            // Shared encoder pass: this block of the padded volume lies in the read region of up to 2 x 2 x 2 overlapping tiles; its image is
+            // copied into each of their per-tile tensors (ConvArgs::sc_boxes), so that the consumer addresses an ordinary per-tile tensor.
+            static_assert(!FIRST || kTX == 16, "lane split of the scatter copy-out");
+            const int t5 = tid >> 3, q = tid & 7;
+            const int x_lane = t5 % kTX, y_lane = t5 / kTX;
+            const bool cok = cb * 4 + n * 2 + (q >> 2) < nco;
+            const size_t tplane = (size_t)a.sc_t[0] * a.sc_t[1] * a.sc_t[2];
+            for (int iz = oz0 / a.sc_e[0]; iz >= 0 && oz0 - iz * a.sc_e[0] < a.sc_t[0]; --iz) {
+                if (iz >= a.sc_g[0]) continue;
+                for (int iy = oy0 / a.sc_e[1]; iy >= 0 && oy0 - iy * a.sc_e[1] < a.sc_t[1]; --iy) {
+                    if (iy >= a.sc_g[1]) continue;
+                    for (int ix = ox0 / a.sc_e[2]; ix >= 0 && ox0 - ix * a.sc_e[2] < a.sc_t[2]; --ix) {
+                        if (ix >= a.sc_g[2]) continue;
+                        const int t = (iz * a.sc_g[1] + iy) * a.sc_g[2] + ix - a.sc_tile0;
+                        if (t < 0 || t >= a.sc_ntiles) continue;
+                        const int lz0 = oz0 - iz * a.sc_e[0], ly0 = oy0 - iy * a.sc_e[1], lx0 = ox0 - ix * a.sc_e[2];      // block origin in tile coordinates
+                        const int* sb = a.sc_boxes + 6 * t;
+                        const int s0z = sb[0] - 1, s0y = sb[1] - 1, s0x = sb[2] - 1, s1z = sb[3] + 1, s1y = sb[4] + 1, s1x = sb[5] + 1;
+                        if (sb[3] <= sb[0] || lz0 >= s1z || lz0 + TZ <= s0z || ly0 >= s1y || ly0 + kTY <= s0y || lx0 >= s1x || lx0 + kTX <= s0x) continue;
+                        unsigned char* ob = outb + ((size_t)t * nco + cb * 4 + n * 2) * tplane * 64;                         // wave-uniform
+                        const long long lane_off = (long long)(((size_t)(q >> 2) * tplane + (size_t)y_lane * a.sc_t[2] + x_lane) * 64 + (q & 3) * 16);
+#pragma unroll
+                        for (int it = 0; it < EIT; ++it) {
+                            const int c = (it & 3) * 32, zc = it >> 2, yc = c / kTX;
+                            const int lz = lz0 + zc, ly = ly0 + y_lane + yc, lx = lx0 + x_lane;
+                            if (cok && lz >= s0z && lz < s1z && ly >= s0y && ly < s1y && lx >= s0x && lx < s1x &&
+                                (unsigned)lz < (unsigned)a.sc_t[0] && (unsigned)ly < (unsigned)a.sc_t[1] && (unsigned)lx < (unsigned)a.sc_t[2]) {
+                                const long long uni = ((long long)(lz * a.sc_t[1] + ly0 + yc) * a.sc_t[2] + lx0) * 64;           // wave-uniform
+                                float4* dstp = reinterpret_cast<float4*>(ob + (lane_off + uni));
+                                const float4 val = *reinterpret_cast<const float4*>(lds + (it * 256 + tid) * 16);
+                                __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                                __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                            }
+                        }
+                    }
+                }
+            }
         } else if (!OAI_DBG_BIT(a, 16)) {
             // Piece sidx = it*256 + tid of the image = 16 bytes (q & 3) of the record (chunk q >> 2) of block voxel w = it*32 + (tid >> 3).
             // kTX * kTY = 128, so z = it >> 2 and the (y, x) of w split into a per-LANE part (from tid >> 3 < 32) and a per-ITERATION part (from
@@ -1051,7 +1089,9 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 template <int COUT>
 __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource s, const float* __restrict__ wk, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, unsigned char* __restrict__ out, int relu,
-                                                               int* __restrict__ range_flag, unsigned* __restrict__ census) {
+                                                               int* __restrict__ range_flag, unsigned* __restrict__ census, int shell) {
+    // shell > 0: only voxels closer than `shell` to a face of the tile are computed (the rest of ec0 comes from the pass over the whole
+    // volume, see run_batch); the exit below is per thread, behind the barrier
     __shared__ __attribute__((aligned(16))) float wl[27 * COUT];
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) wl[i] = wk[i];
     __syncthreads();
@@ -1059,8 +1099,32 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
     const int local_tile = blockIdx.y;
     const int hw = s.tw >> 1;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= plane / 2) return;
-    const int x = 2 * (int)(p % hw), y = (int)((p / hw) % s.th), z = (int)(p / ((size_t)hw * s.th));
+    int x, y, z;
+    bool live;
+    if (shell <= 0) {
+        live = p < plane / 2;
+        x = 2 * (int)(p % hw); y = (int)((p / hw) % s.th); z = (int)(p / ((size_t)hw * s.th));
+    } else {
+        // only the voxel pairs closer than `shell` to a face, enumerated slab by slab (see first_shell_pairs): two z slabs of `shell`
+        // slices, between them two y slabs of `shell` rows, between those the first and last ceil(shell / 2) x pairs of every row
+        const int sh2 = 2 * shell, ps = (shell + 1) / 2;
+        const size_t nA = (size_t)sh2 * s.th * hw, nB = (size_t)(s.td - sh2) * sh2 * hw, nC = (size_t)(s.td - sh2) * (s.th - sh2) * 2 * ps;
+        live = p < nA + nB + nC;
+        if (p < nA) {
+            const int zi = (int)(p / ((size_t)s.th * hw));
+            z = zi < shell ? zi : s.td - sh2 + zi; y = (int)((p / hw) % s.th); x = 2 * (int)(p % hw);
+        } else if (p < nA + nB) {
+            const size_t q = p - nA;
+            const int yi = (int)((q / hw) % sh2);
+            z = shell + (int)(q / ((size_t)sh2 * hw)); y = yi < shell ? yi : s.th - sh2 + yi; x = 2 * (int)(q % hw);
+        } else {
+            const size_t q = live ? p - nA - nB : 0;
+            const int xi = (int)(q % (2 * ps));
+            z = shell + (int)(q / ((size_t)(s.th - sh2) * 2 * ps)); y = shell + (int)((q / (2 * ps)) % (s.th - sh2));
+            x = xi < ps ? 2 * xi : s.tw - 2 * ps + 2 * (xi - ps);
+        }
+    }
+    const bool inner = !live;
     int iz[3], iy[3], ix[4];
     const float* base;
     if (s.vol) {
@@ -1092,6 +1156,8 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
         }
         base = s.tiles + (size_t)local_tile * plane;
     }
+    float rmax = 0.0f;
+    if (!inner) {
     float acc[2][COUT];
 #pragma unroll
     for (int j = 0; j < COUT; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
@@ -1118,7 +1184,6 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
     }
     constexpr int NCH = (COUT + 15) / 16;
     const size_t v = ((size_t)z * s.th + y) * s.tw + x;
-    float rmax = 0.0f;
 #pragma unroll
     for (int vv = 0; vv < 2; ++vv) {
 #pragma unroll
@@ -1141,36 +1206,77 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
             *reinterpret_cast<u16x8*>(o + 48) = lo[1];
         }
     }
+    }
     census_note(census, range_flag, rmax);      // (whole blocks leave at the top: plane / 2 is a multiple of 256)
 }
 
 // ---- MaxPool3d(2) on format S (fallback when the pooling cannot ride in the conv epilogue) -----------------------------------
+// shell_only: just the pooled voxels on the faces of the tile (their 2 x 2 x 2 windows are what the per-tile shell launches of ec1 wrote)
 __global__ void __launch_bounds__(256) maxpool2_sres_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
-                                                            int D, int H, int W, int nch, size_t total /*out voxels * nch * 4*/) {
+                                                            int D, int H, int W, int nch, size_t total /*out voxels * nch * 4*/, int shell_only) {
     const int Do = D / 2, Ho = H / 2, Wo = W / 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i & 3);
         size_t rec = i >> 2;
         const int ch = (int)(rec % nch);
         size_t v = rec / nch;
-        const int x = (int)(v % Wo); v /= Wo;
-        const int y = (int)(v % Ho); v /= Ho;
-        const int z = (int)(v % Do);
-        const size_t tile = v / Do;
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int x, y, z;
+        size_t tile;
+        if (!shell_only) {
+            x = (int)(v % Wo); v /= Wo;
+            y = (int)(v % Ho); v /= Ho;
+            z = (int)(v % Do);
+            tile = v / Do;
+        } else {                                   // `total` counts face voxels only: two z faces, between them two y faces, between those two x faces
+            const size_t nA = (size_t)2 * Ho * Wo, nB = (size_t)(Do - 2) * 2 * Wo, nC = (size_t)(Do - 2) * (Ho - 2) * 2;
+            const size_t skipA = shell_only == 2 ? nA : 0;      // 2: the z faces were pooled in the epilogue of their own launches
+            size_t f = v % (nA + nB + nC - skipA) + skipA;
+            tile = v / (nA + nB + nC - skipA);
+            if (f < nA) { z = f < (size_t)Ho * Wo ? 0 : Do - 1; y = (int)((f / Wo) % Ho); x = (int)(f % Wo); }
+            else if (f < nA + nB) { f -= nA; z = 1 + (int)(f / (2 * Wo)); y = (f / Wo) % 2 ? Ho - 1 : 0; x = (int)(f % Wo); }
+            else { f -= nA + nB; z = 1 + (int)(f / ((size_t)(Ho - 2) * 2)); y = 1 + (int)((f / 2) % (Ho - 2)); x = f % 2 ? Wo - 1 : 0; }
+        }
+        // The pooled record is the stored (hi, lo) PAIR of the window's largest element -- not a re-split of the joined maximum: the fused
+        // pool of the conv epilogue splits max(x_i) of the unrounded values, which is exactly the pair the arg-max element was stored as;
+        // re-splitting h0 + h1 can return the other representation of the same value when h1 is half an ulp of h0 (a tie), and the a1.b1 term
+        // the arithmetic drops then differs.  Equal joined values: the larger hi came from the larger unrounded value (it rounded up).
+        float m[4];
+        u16x4 hi, lo;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const unsigned char* p = in + srec(tile, nch, (size_t)D * H * W, ch, (((size_t)(2 * z + (k >> 2))) * H + 2 * y + ((k >> 1) & 1)) * W + 2 * x + (k & 1));
-            const u16x4 hi = *reinterpret_cast<const u16x4*>(p + q * 8), lo = *reinterpret_cast<const u16x4*>(p + 32 + q * 8);
+            const u16x4 h = *reinterpret_cast<const u16x4*>(p + q * 8), l = *reinterpret_cast<const u16x4*>(p + 32 + q * 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], join2_f16(hi[j], lo[j]));
+            for (int j = 0; j < 4; ++j) {
+                const float v = join2_f16(h[j], l[j]);
+                const bool better = k == 0 || v > m[j] || (v == m[j] && (float)__builtin_bit_cast(_Float16, h[j]) > (float)__builtin_bit_cast(_Float16, hi[j]));
+                if (better) { m[j] = v; hi[j] = h[j]; lo[j] = l[j]; }
+            }
         }
-        u16x4 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { unsigned l; hi[j] = (unsigned short)split2_f16(m[j], l); lo[j] = (unsigned short)l; }
         unsigned char* o = out + srec(tile, nch, (size_t)Do * Ho * Wo, ch, ((size_t)z * Ho + y) * Wo + x);
         *reinterpret_cast<u16x4*>(o + q * 8) = hi;
         *reinterpret_cast<u16x4*>(o + 32 + q * 8) = lo;
+    }
+}
+
+// ---- interior of a per-tile pooled tensor out of the volume-wide one (shared ec0 -> ec1 pass): 16 bytes per thread -------------------------
+// out[tile][chunk][z][y][x] = shared[chunk][tz/2 + z][ty/2 + y][tx/2 + x] for the pooled voxels NOT on a face of the tile
+__global__ void __launch_bounds__(256) pooled_gather_kernel(const unsigned char* __restrict__ shared, unsigned char* __restrict__ out, TileSource g,
+                                                            int Dp, int Hp, int Wp, int sDp, int sHp, int sWp, int nch, size_t total /*tiles * voxels * nch * 4*/) {
+    const size_t pvox = (size_t)Dp * Hp * Wp, spl = (size_t)sDp * sHp * sWp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);
+        size_t rec = i >> 2;
+        const int x = (int)(rec % Wp); rec /= Wp;
+        const int y = (int)(rec % Hp); rec /= Hp;
+        const int z = (int)(rec % Dp); rec /= Dp;
+        const int ch = (int)(rec % nch);
+        const size_t tile = rec / nch;
+        if (z == 0 || z == Dp - 1 || y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) continue;      // faces: written by the per-tile shell pass
+        const int t = g.tile_begin + (int)tile;
+        const int tz = (t / (g.gx * g.gy)) * g.ez / 2, ty = ((t / g.gx) % g.gy) * g.ey / 2, tx = (t % g.gx) * g.ex / 2;
+        const uint4 v = *reinterpret_cast<const uint4*>(shared + ((size_t)ch * spl + ((size_t)(tz + z) * sHp + ty + y) * sWp + tx + x) * 64 + q * 16);
+        *reinterpret_cast<uint4*>(out + srec(tile, nch, pvox, ch, ((size_t)z * Hp + y) * Wp + x) + q * 16) = v;
     }
 }
 

@@ -107,8 +107,13 @@ class UNetEngine:
             self._h = None
 
     # ------------------------------------------------------------------------------------------
-    def _workspace(self, tile_zyx, batch) -> torch.Tensor:
-        need = int(self.lib.oai_unet_workspace_bytes(self._h, *[int(v) for v in tile_zyx], int(batch)))
+    def _workspace(self, tile_zyx, batch, size_zyx=None, overlap_zyx=None) -> torch.Tensor:
+        """Activation workspace for `batch` tiles; with the volume's geometry also the two volume-wide tensors of the shared encoder pass
+        (oai_segment_workspace_bytes: without them oai_segment_tiles computes ec0 -> ec1 per tile; same results)."""
+        if size_zyx is not None:
+            need = int(self.lib.oai_segment_workspace_bytes(self._h, *[int(v) for v in size_zyx], _lib.int3(tile_zyx), _lib.int3(overlap_zyx), int(batch)))
+        else:
+            need = int(self.lib.oai_unet_workspace_bytes(self._h, *[int(v) for v in tile_zyx], int(batch)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -127,7 +132,7 @@ class UNetEngine:
         return n
 
     def set_option(self, name: str, value: int) -> None:
-        """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds": include/oai_hip.h)."""
+        """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census": include/oai_hip.h)."""
         _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
 
     def range_flag(self, reset: bool = True) -> int:
@@ -259,7 +264,7 @@ class UNetEngine:
         if self._needs_calibration():
             # on the WHOLE volume whatever range was asked for: every rank of a tile-sharded volume arrives at the same exponents
             self.calibrate_volume(vol, tile_zyx, overlap_zyx, crop_zyx, batch=None if (begin, end) != (0, ntiles) else batch)
-        ws = self._workspace(tile_zyx, batch)
+        ws = self._workspace(tile_zyx, batch, (D, H, W), overlap_zyx)
         blocks = torch.empty((end - begin, self.n_classes, *eff), dtype=torch.float32, device=self.device)
         if end > begin:
             self._launch_segment(vol, tile_zyx, overlap_zyx, crop_zyx, begin, end, out_mode, blocks, batch, ws)
@@ -279,7 +284,7 @@ class UNetEngine:
         vol = vol.to(self.device, torch.float32).contiguous()
         eff, grid, ntiles = tile_grid(vol.shape, tile_zyx, overlap_zyx)
         batch = max(1, min(int(batch or self.auto_batch(tile_zyx, ntiles)), ntiles))
-        ws = self._workspace(tile_zyx, batch)
+        ws = self._workspace(tile_zyx, batch, vol.shape, overlap_zyx)
         blocks = torch.empty((ntiles, self.n_classes, *eff), dtype=torch.float32, device=self.device)
         return self.calibrate(lambda: self._launch_segment(vol, tile_zyx, overlap_zyx, crop_zyx, 0, ntiles, 0, blocks, batch, ws))
 

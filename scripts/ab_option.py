@@ -1,5 +1,5 @@
 """A/B of a result-preserving option on one box: full-size segmentation (160 tiles, fp16x3), alternating the values, with a bit-identity
-check of the tile outputs.   usage: python scripts/ab_option.py <option> <v0,v1,...> [reps]"""
+check of the stitched maps (the raw blocks hold unspecified values where the frame is zeroed).   usage: python scripts/ab_option.py <option> <v0,v1,...> [reps]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oai_analysis_2_amd.synth import make_unet_state_dict, make_volume
@@ -17,5 +17,6 @@ for rep in range(REPS):
             out = eng.segment_tiles(vol, (32, 128, 128), (8, 16, 16), None, 0, 160, (8, 16, 16))
         torch.cuda.synchronize()
         dt = (time.time() - t) / 3
-        if ref is None: ref = out.clone()
-        print(f"{OPT}={v}: {dt*1e3:.1f} ms per volume (segmentation only), equal to first: {torch.equal(out, ref)}", flush=True)
+        maps = eng.stitch(out, vol.shape, (32, 128, 128), (8, 16, 16), (8, 16, 16))
+        if ref is None: ref = maps.clone()
+        print(f"{OPT}={v}: {dt*1e3:.1f} ms per volume (segmentation only), equal to first: {torch.equal(maps, ref)}", flush=True)

@@ -93,6 +93,14 @@ def test_full_volume_properties(full):
     assert max(work) - min(work) <= max(costs) and ranges[0][1] - ranges[0][0] > 20
     parts = [eng.segment_tiles(v, TILE, OVL, rg, 0, 24, CROP) for rg in ranges]
     assert torch.equal(eng.stitch(torch.cat(parts), SHAPE, TILE, OVL, CROP), prob)
+    # ec0 -> ec1 once over the reflect-padded volume + a 2-voxel shell per tile (the default, "shared_enc") == every tile on its own
+    if full["precision"] == "fp16x3":
+        eng.set_option("shared_enc", 0)
+        per_tile = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=0, crop_zyx=CROP), SHAPE, TILE, OVL, CROP)
+        eng.set_option("shared_enc", 1)
+        assert torch.equal(per_tile, prob)
+        lg = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=2, crop_zyx=CROP), SHAPE, TILE, OVL, CROP)
+        assert torch.equal(lg, logits)
     # border-tile trimming off (crop unknown to the segment call) computes more but stitches to the same maps
     untrimmed = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=0, batch=16), SHAPE, TILE, OVL, CROP)
     assert torch.equal(untrimmed, prob)

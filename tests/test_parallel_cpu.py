@@ -171,6 +171,17 @@ def _worker_queue(rank, world, port, n, out_dir):
     assert q.claim() is None
     q2 = parallel.VolumeQueue(5)                                  # a second queue gets its own key on every rank
     got2 = list(q2)
+    assert q.claimed == got and q2.claimed == got2                 # what this rank took is recorded (a driver can re-issue lost volumes)
+    # a queue that the ranks construct with different sizes (e.g. in rank-conditional code) is refused instead of silently skipping volumes
+    dist.barrier()
+    try:
+        parallel.VolumeQueue(7 if rank == 0 else 8, name="mismatched")
+        ok = rank == 0 or None                                    # the rank that creates the key cannot know; every other rank must raise
+    except RuntimeError:
+        ok = True
+    dist.barrier()
+    created_first = int(dist.distributed_c10d._get_default_store().get("mismatched_n"))
+    assert ok is True or created_first == (7 if rank == 0 else 8), "a size mismatch went unnoticed"
     with open(os.path.join(out_dir, f"q_{rank}"), "w") as f:
         f.write(",".join(map(str, got)) + ";" + ",".join(map(str, got2)))
     dist.barrier()
