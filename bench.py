@@ -39,7 +39,7 @@ DTYPE_OF = {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 ter
             "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
             "fp16x3": "fp16x3 (every fp32 value held as 2 fp16 terms = 22 mantissa bits, 3 MFMA passes per product, fp32 accumulate; "
                       "fp32 in and out of every entry point; full-size parity vs the reference in `parity`)"}
-TRAFFIC_FILE = {"f32": "profiles/r01_pmc_traffic.json", "fp16x3": "profiles/r02_pmc_traffic_sres.json"}
+TRAFFIC_FILE = {"f32": "profiles/r03_pmc_traffic_f32.json", "fp16x3": "profiles/r03_pmc_traffic_sres.json"}
 
 
 def physical_cores() -> int:
@@ -439,8 +439,9 @@ def main():
         def traffic_of(prec):     # HBM-side bytes per launch: PMC counters need their own rocprofv3 passes, so this is READ FROM profiles/
             try:
                 with open(os.path.join(ROOT, TRAFFIC_FILE[prec])) as f:
-                    # the counters were collected on 32-tile passes; a launch of this run covers `last_batch` tiles
-                    return json.load(f)["bytes_per_launch"] * getattr(unet, "last_batch", 32) / 32.0
+                    # the counters were collected on passes of `tiles_per_pass` tiles (160: this run's launch size); a launch here covers `last_batch`
+                    js = json.load(f)
+                    return js["bytes_per_launch"] * getattr(unet, "last_batch", 160) / float(js.get("tiles_per_pass", 32))
             except (OSError, KeyError, ValueError):
                 return None
 
@@ -451,7 +452,7 @@ def main():
             peak = MFMA_F32_PEAK_TFLOPS if prec == "f32" else MFMA_BF16_PEAK_TFLOPS
             return {"bound": "mfma", "kernel": KERNEL_OF[prec], "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": traffic_of(prec),
-                    "traffic_source": (TRAFFIC_FILE.get(prec, "none") + " (rocprofv3 --pmc, separate pass, 32-tile launches scaled to this launch size; "
+                    "traffic_source": (TRAFFIC_FILE.get(prec, "none") + " (rocprofv3 --pmc, separate passes of this round's library at this launch size; "
                                        "NOT measured in this run)") if traffic_of(prec) is not None else None,
                     "achieved_frame_aware": ach_fa, "frac_frame_aware": ach_fa / peak,
                     "mfma_passes_per_product": PASSES[prec], "executed_frac": ach_fa * PASSES[prec] / peak,

@@ -7,17 +7,23 @@ GF = {"ec1": 58.0, "ec2": 14.5, "ec3": 29.0, "ec4": 7.25, "ec5": 14.5, "ec6": 3.
 ORDER = ["ec1", "ec2", "ec3", "ec4", "ec5", "ec6", "ec7", "dc9 (up)", "dc8", "dc7", "dc6 (up)", "dc5", "dc4", "dc3 (up)", "dc2", "dc1"]
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"]]
-if starts: rows = rows[starts[-1]:]
-else:                                                   # ec0 fused into ec1: a pass starts at the FIRST instantiation of the conv kernel
-    starts = [i for i, r in enumerate(rows) if "conv3_igemm_sres" in r["Kernel_Name"] and "false, true" in r["Kernel_Name"]]
+fused = [i for i, r in enumerate(rows) if "conv3_igemm_sres<" in r["Kernel_Name"] and "false, true" in r["Kernel_Name"]]
+if fused: rows = rows[fused[-1]:]                        # ec0 fused into ec1 (per tile, or the shared pass over the padded volume): a pass starts at the FIRST instantiation
+else:
+    starts = [i for i, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"]]
     rows = rows[starts[-1]:]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 layers, cur = [], None
+# shared encoder pass (round 3): the FIRST launch over the padded volume is followed by pooled_gather, the ec0 shell, six face launches and the
+# pooled faces -- all of it is "ec1"
+if len(rows) > 1 and "pooled_gather" in rows[1]["Kernel_Name"]:
+    k = next(i for i, r in enumerate(rows) if "maxpool2_sres" in r["Kernel_Name"])
+    layers.append([None, sum(dur(r) for r in rows[:k + 1]), k + 1]); cur = layers[-1]
+    rows = rows[k + 1:]
 for r in rows:
     n = r["Kernel_Name"]
     main = "conv3_igemm_sres<4, 16, 2, 4, 1" in n or "conv3_igemm_sres2<16, 2, 4, 1" in n
-    if "conv3_first" in n: layers.append(["ec0", dur(r), 1]); continue
+    if "conv3_first" in n and not fused: layers.append(["ec0", dur(r), 1]); continue
     if "upconv2" in n or main: layers.append([None, dur(r), 1]); cur = layers[-1]; continue
     if "conv3_igemm_sres" in n and cur is not None: cur[1] += dur(r); cur[2] += 1; continue      # strip launches belong to the layer before them
     layers.append([n[:40], dur(r), 1])
