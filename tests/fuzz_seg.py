@@ -31,3 +31,37 @@ for case in range(int(os.environ.get("CASES", "12"))):
     print(f"case {case}: width/{wd} bn={bn} tile {tile} ovl {ovl} volume {shape}: max|dp| {err:.2e} overflow={eng.range_overflow()}")
     assert err < 1e-5, "fp16x3 differs from the oracle"
 print("worst", worst)
+
+# ---- geometries that take the shared encoder pass (ec0 -> ec1 once over the padded volume + a shell per tile): tile % (4, 8, 16) == 0,
+# (tile - 2 overlap) % (4, 8, 16) == 0, overlap >= 4, reference width.  Random ragged volumes, batch sizes (partial z ranges of the pass) and tile
+# ranges; the stitched maps must EQUAL the per-tile computation bit for bit and match the oracle.
+worst = 0.0
+for case in range(int(os.environ.get("SHARED_CASES", "10"))):
+    tile = (int(rng.choice([16, 24, 32])), int(rng.choice([24, 32, 40, 48])), int(rng.choice([32, 48, 64])))
+    ovl = (int(rng.choice([4, 6])), int(rng.choice([4, 8])), 8)
+    if any(t - 2 * o <= 0 or (t - 2 * o) % b for t, o, b in zip(tile, ovl, (4, 8, 16))):
+        continue
+    shape = tuple(int(rng.integers(t - 2 * o + 1, 3 * (t - 2 * o) + 2 * o)) for t, o in zip(tile, ovl))
+    sd = make_unet_state_dict(seed=50 + case, width_div=1, bn=bool(rng.integers(0, 2)))
+    vol = make_volume(200 + case, shape)
+    v = torch.from_numpy(vol).cuda()
+    crop = (ovl[0], ovl[2], ovl[1])                                               # the reference's crop order (as in the loop above)
+    fc_ref, tc_ref = oseg.segment(vol, sd, tile[::-1], ovl[::-1], output_prob=True)
+    eng = UNetEngine(sd, precision="fp16x3")
+    batch = int(rng.integers(1, 12))
+    res = {}
+    for sh in (1, 0):
+        eng.set_option("shared_enc", sh)
+        res[sh] = eng.stitch(eng.segment_tiles(v, tile, ovl, out_mode=0, batch=batch, crop_zyx=crop), shape, tile, ovl, crop)
+    ntiles = res[1].numel() and int(np.prod([-(-s // (t - 2 * o)) for s, t, o in zip(shape, tile, ovl)]))
+    cut = int(rng.integers(1, max(2, ntiles)))
+    eng.set_option("shared_enc", 1)
+    parts = torch.cat([eng.segment_tiles(v, tile, ovl, (0, cut), 0, batch, crop), eng.segment_tiles(v, tile, ovl, (cut, ntiles), 0, batch, crop)]) if cut < ntiles else None
+    eq_parts = parts is None or torch.equal(eng.stitch(parts, shape, tile, ovl, crop), res[1])
+    maps = res[1].cpu().numpy()
+    err = max(np.abs(maps[0] - fc_ref).max(), np.abs(maps[1] - tc_ref).max())
+    worst = max(worst, err)
+    print(f"shared case {case}: tile {tile} ovl {ovl} volume {shape} batch {batch} ({ntiles} tiles, split at {cut}): shared == per-tile {torch.equal(res[1], res[0])}, "
+          f"tile ranges == whole {eq_parts}, max|dp| vs oracle {err:.2e}, flag {eng.range_flag()}")
+    assert torch.equal(res[1], res[0]) and eq_parts and err < 1e-5
+print("worst (shared)", worst)
