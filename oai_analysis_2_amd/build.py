@@ -89,7 +89,25 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), lib
             print(f"[oai build] linked {LIB}", file=sys.stderr)
         if not packed_tu:
             check_no_packed_fp32(LIB)
+        check_no_sgpr_hazard(LIB)
     return LIB
+
+
+def check_no_sgpr_hazard(lib: str) -> None:
+    """The build FAILS if a VMEM instruction reads an SGPR that a VALU instruction (v_readfirstlane / v_readlane / v_cmp) wrote fewer than
+    five wait states earlier.  hipcc pads its own code; it does not look inside inline assembly (gload16_asm: `global_load_dwordx4 v, v,
+    s[b:b+1]`), where the stale SGPR is a wild address (csrc/unet_sres2.h: sgpr_settle)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sgpr_hazard_scan", os.path.join(os.path.dirname(HERE), "scripts", "sgpr_hazard_scan.py"))
+    if not os.path.exists(spec.origin) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        print("[oai build] WARNING: the SGPR-hazard guard did not run", file=sys.stderr)
+        return
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hits = mod.scan_library(lib)
+    if hits:
+        os.remove(lib)
+        raise RuntimeError("VALU-written SGPR read by a VMEM instruction too early (inline assembly?):\n" + "\n".join(hits))
 
 
 def check_no_packed_fp32(lib: str) -> None:

@@ -11,6 +11,7 @@
 #include "unet_kernels.h"
 #include "unet_sres.h"
 #include "unet_sres2.h"
+#include "unet_wino.h"
 
 namespace oai {
 
@@ -32,6 +33,8 @@ struct Layer {
     std::vector<float> ws;              // per-cout weight scale of the fp16 panel (exact powers of two)
     int rel1 = 0;                       // exponent folded into the source-1 (skip) weights of the current fp16 panel: e(src0) - e(src1)
     size_t panel_f16_floats = 0;
+    float4* panel_wino = nullptr;       // fp16 panel of conv3_wino_sres (pack_wino_panel): the x axis in Winograd F(2,3) form; packed with the same ws / rel1
+    size_t panel_wino_floats = 0;
     std::vector<float> wk_host;         // canonical [27][cin][cout] weights of the k3 layers (for re-packing)
     std::vector<float> scale_host, shift_host, plain_host;
     float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
@@ -56,6 +59,8 @@ struct oai_unet {
     bool calibrated = false;
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
+    int opt_wino = 0;                   // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs)
+    int opt_wino_layers = 0x3FFFF;      // option "winograd_layers": bit k = layer k may take the Winograd kernel (A/B of single layers)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
@@ -214,6 +219,43 @@ static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int 
     return out;
 }
 
+// Panel of conv3_wino_sres (unet_wino.h): [cb][frequency f][chunk of 16][tap (dz, dy)][term][nr][lane] x 8 fp16, lane (half h, column j) =
+// channels 8h..8h+7 of the chunk for cout cb*64+nr*32+j, of the x-transformed weights
+//   u0 = g0, u1 = (g0 + g1 + g2) / 2, u2 = (g0 - g1 + g2) / 2, u3 = g2     (g = the three x taps of (dz, dy, cin, cout)),
+// formed in double from the scaled weights (wscale, src1_factor: see pack_conv3_panel_bf), rounded to fp32 once, then split.
+static std::vector<float> pack_wino_panel(const std::vector<float>& wk, int C0, int C1, int Cout, const std::vector<float>& wscale, float src1_factor) {
+    const int Cin = C0 + C1, KC = 16;
+    const int ncb = Cout / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+    const size_t units = ((size_t)ncb * 4 * (nch0 + nch1) * 9 + 1) * 2 * 2 * 64;      // 16-byte units, +1 tap of prefetch slack
+    std::vector<float> out(units * 4, 0.0f);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+    size_t u = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int f = 0; f < 4; ++f)
+            for (int ch = 0; ch < nch0 + nch1; ++ch) {
+                const bool first = ch < nch0;
+                const int Csrc = first ? C0 : C1, cofs = first ? 0 : C0, cl0 = (first ? ch : ch - nch0) * KC;
+                for (int t = 0; t < 9; ++t)                          // t = dz * 3 + dy
+                    for (int k = 0; k < 2; ++k)
+                        for (int nr = 0; nr < 2; ++nr)
+                            for (int lane = 0; lane < 64; ++lane, ++u)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int cl = cl0 + 8 * (lane >> 5) + j;
+                                    const int co = cb * 64 + nr * 32 + (lane & 31);
+                                    if (cl >= Csrc) continue;
+                                    double g[3];
+                                    for (int dx = 0; dx < 3; ++dx)
+                                        g[dx] = (double)wk[((size_t)(t * 3 + dx) * Cin + cofs + cl) * Cout + co] * (double)wscale[co] * (first ? 1.0 : (double)src1_factor);
+                                    const double uf = f == 0 ? g[0] : f == 1 ? 0.5 * (g[0] + g[1] + g[2]) : f == 2 ? 0.5 * (g[0] - g[1] + g[2]) : g[2];
+                                    float r = (float)uf;
+                                    uint16_t b = 0;
+                                    for (int kk = 0; kk <= k; ++kk) { b = f32_to_f16_rne(r); r -= f16_to_f32(b); }
+                                    o16[u * 8 + j] = b;
+                                }
+            }
+    return out;
+}
+
 // [N/64][Cin/8][2][lane] x float4 for upconv2_igemm_f32; column n = parity*Cout + co
 static std::vector<float> pack_up_panel(const oai_layer_params& p) {
     const int N = 8 * p.cout, nnb = (N + 63) / 64, nkg = (p.cin + 7) / 8;
@@ -284,6 +326,16 @@ static int upload_into(oai_unet* h, const std::vector<float>& v, T** dst) {
 static inline int layer_src0(int k) { return k - 1; }
 static inline int layer_src1(int k) { return k == DC8 ? EC5 : k == DC5 ? EC3 : k == DC2 ? EC1 : -1; }
 
+// The Winograd panel of layer k (k3 layers with whole blocks of 64 couts) for the weight scales / skip exponent of its current fp16 panel
+static int pack_wino_layer(oai_unet* h, int k) {
+    Layer& L = h->L[k];
+    if (L.kind == 2 || L.wk_host.empty() || L.cout % 64 != 0 || L.ws.empty()) return OAI_OK;
+    const std::vector<float> panel = pack_wino_panel(L.wk_host, L.c0, L.c1, L.cout, L.ws, ldexpf(1.0f, L.rel1));
+    if (L.panel_wino && panel.size() != L.panel_wino_floats) return set_error(OAI_ERR_ARG, "Winograd panel of layer %d changed size", k);
+    L.panel_wino_floats = panel.size();
+    return upload_into(h, panel, &L.panel_wino);
+}
+
 // The fp16 panel of layer k (k3 conv or k2s2 up-conv) for the current activation exponents.  Every output channel's weights are scaled
 // by the power of two that puts max|w| in [2^7, 2^8) -- exact, undone by the epilogue scale -- so that the low split term of all
 // weights down to 2^-11 of the largest stays in fp16's normal range.
@@ -316,7 +368,8 @@ static int pack_fp16_layer(oai_unet* h, int k) {
     if (L.panel_bf[2] && panel.size() != L.panel_f16_floats) return set_error(OAI_ERR_ARG, "fp16 panel of layer %d changed size", k);
     L.panel_f16_floats = panel.size();
     L.rel1 = rel1;
-    return upload_into(h, panel, &L.panel_bf[2]);
+    if (int rc = upload_into(h, panel, &L.panel_bf[2])) return rc;
+    return (h->opt_wino || L.panel_wino) ? pack_wino_layer(h, k) : OAI_OK;
 }
 
 // The fp16x3 epilogue arrays of every layer for the current activation exponents (see Layer::scale_f16).  ec0 reads the raw volume
@@ -554,6 +607,69 @@ static int launch_conv3_one(const oai_unet* h, const Layer& L, const float* s0, 
     return launch_conv3_shape<4, 8, RX, RY, WY, WX>(h, a, box, ntiles, st, pool_only ? 2 : 0);
 }
 
+// One launch of conv3_wino_sres (unet_wino.h) with blocks of 4 x TY x 2 NP over `box` (box.lo[2] even)
+template <int TY, int NP>
+static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
+    for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
+    if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
+    const int ng = a.Cout % 128 == 0 ? 2 : 1;
+    a.wpanel = L.panel_wino;
+    a.ncb = a.Cout / (64 * ng);
+    a.nbz = cdiv(box.hi[0] - box.lo[0], 4); a.nby = cdiv(box.hi[1] - box.lo[1], TY); a.nbx = cdiv(box.hi[2] - box.lo[2], 2 * NP);
+    unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    if (h->xcd_group > 0) {
+        a.nblocks = (int)grid; a.xcd_group = h->xcd_group;
+        const unsigned q = 8u * (unsigned)h->xcd_group;
+        grid = (grid + q - 1) / q * q;
+    }
+    oai_unet* hm = const_cast<oai_unet*>(h);
+    if (h->profile) {
+        if (hm->ev_used + 2 > hm->ev_pool.size()) {
+            hipEvent_t e0, e1;
+            OAI_CHECK_HIP(hipEventCreate(&e0));
+            OAI_CHECK_HIP(hipEventCreate(&e1));
+            hm->ev_pool.push_back(e0);
+            hm->ev_pool.push_back(e1);
+        }
+        OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
+    }
+    if (ng == 2) conv3_wino_sres<2, TY, NP><<<grid, 512, 0, st>>>(a, h->zero_rec);
+    else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);       // one block of 64 couts: the eight waves split the z slices
+    OAI_CHECK_LAUNCH();
+    if (h->profile) {
+        OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
+        hm->ev_used += 2;
+    }
+    return OAI_OK;
+}
+
+// A plain layer (no fused ec0 / pool / head / scatter) of the default split-resident configuration through conv3_wino_sres: main blocks of
+// 4 x 8 x 8, a y strip of 4 x 4 x 16 blocks for a remainder of <= 4 rows, an x strip of 4 x 16 x 4 blocks for a remainder of <= 4 columns
+// .  The box starts at an even x: an output's arithmetic depends on the
+// parity of its x only -- not on which launch or block computes it.
+static int launch_conv3_wino(const oai_unet* h, const Layer& L, const ConvArgs& a, Box box, int ntiles, hipStream_t st) {
+    box.lo[2] &= ~1;
+    const int ry = box.hi[1] - box.lo[1], rx = box.hi[2] - box.lo[2];
+    int ny = ry / 8, nx = rx / 8, hr = ry - 8 * ny, wr = rx - 8 * nx;
+    if (ny == 0 || nx == 0) { ny = cdiv(ry, 8); nx = cdiv(rx, 8); hr = wr = 0; }
+    if (hr > 4) { ++ny; hr = 0; }
+    if (wr > 4) { ++nx; wr = 0; }
+    Box main = box, xs = box, ys = box;
+    main.hi[1] = hr ? box.lo[1] + 8 * ny : box.hi[1];
+    main.hi[2] = wr ? box.lo[2] + 8 * nx : box.hi[2];
+    if (int rc = launch_wino_shape<8, 4>(h, L, a, main, ntiles, st)) return rc;
+    if (wr) {                                 // x strip: all y rows, the last wr columns
+        xs.lo[2] = main.hi[2];
+        if (int rc = launch_wino_shape<16, 2>(h, L, a, xs, ntiles, st)) return rc;
+    }
+    if (hr) {                                 // y strip: the last hr rows, main columns only
+        ys.lo[1] = main.hi[1];
+        ys.hi[2] = main.hi[2];
+        if (int rc = launch_wino_shape<4, 8>(h, L, a, ys, ntiles, st)) return rc;
+    }
+    return OAI_OK;
+}
+
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
                         const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
                         float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr,
@@ -561,6 +677,9 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     ConvArgs a;
     if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
+    if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.pool_out && !a.sc_boxes &&
+        a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
+        return launch_conv3_wino(h, L, a, box, ntiles, st);
     int ny, nx, hr, wr;
     strip_plan(h, box, ny, nx, hr, wr);
     Box main = box, xs = box, ys = box;
@@ -984,6 +1103,18 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "wide")) {
         OAI_CHECK_ARG(value >= 0 && value <= 2, "oai_unet_set_option: wide must be 0, 1 or 2 (2 = also for launches of fewer than 1024 workgroups)");
         h->opt_wide = value;
+    } else if (!strcmp(name, "winograd")) {            // bit 0: layers with Cout % 128 == 0 (two cout groups per workgroup), bit 1: Cout % 128 == 64
+        OAI_CHECK_ARG(value >= 0 && value <= 3, "oai_unet_set_option: winograd must be in [0, 3]");
+        if (value && !h->opt_wino && h->L[EC0].scale_f16) {
+            OAI_CHECK_HIP(hipDeviceSynchronize());
+            for (int k = 1; k < 17; ++k)
+                if (h->L[k].panel_bf[2] && !h->L[k].panel_wino)
+                    if (int rc = pack_wino_layer(h, k)) return rc;
+        }
+        h->opt_wino = value;
+    } else if (!strcmp(name, "winograd_layers")) {
+        OAI_CHECK_ARG(value >= 0 && value <= 0x3FFFF, "oai_unet_set_option: winograd_layers is a mask over the 18 layers");
+        h->opt_wino_layers = value;
     } else if (!strcmp(name, "dead_stores")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: dead_stores must be 0 or 1");
         h->opt_dead_stores = value;

@@ -35,6 +35,11 @@ __device__ __forceinline__ f32x4 gload16_asm(const void* sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
     return v;
 }
+// "VALU writes an SGPR -> VMEM reads it" needs five wait states, and the compiler's hazard recognizer does not look inside inline assembly:
+// a uniform base made by v_readfirstlane (or reloaded from an SGPR spill lane by v_readlane) right in front of gload16_asm would be read
+// STALE -- a wild address (conv3_wino_sres faulted that way on some layers).  sgpr_settle(base) in front of the first load behind such a
+// write; the build refuses a library in which any candidate is left (build.py: check_no_sgpr_hazard, scripts/sgpr_hazard_scan.py).
+__device__ __forceinline__ void sgpr_settle(const unsigned char*& sbase) { asm volatile("s_nop 4" : "+s"(sbase) :: "memory"); }     // (tied to the SGPR pair: its producer stays in front, its readers behind)
 // s_waitcnt vmcnt(N) that "produces" the four weight fragments: every later use of them is ordered behind the wait
 template <int N>
 __device__ __forceinline__ void vm_wait(f32x4& b0, f32x4& b1, f32x4& b2, f32x4& b3) {
@@ -141,6 +146,7 @@ __global__ void __launch_bounds__(512, 1) conv3_igemm_sres2(const ConvArgs a, co
 #pragma unroll
     for (int it = 0; it < NIT; ++it) issue_piece(it, 0, 0);
     f32x4 bq[NB][2][NREP];                                          // [tap % NB][term][n]
+    sgpr_settle(wp);                                                // wp has just been made uniform by v_readfirstlane
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll

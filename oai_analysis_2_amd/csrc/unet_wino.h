@@ -1,0 +1,495 @@
+// conv3_wino_sres: the split-resident 3x3x3 conv with the x axis in Winograd F(2,3) form -- two thirds of the matrix work.
+//
+// The fp16x3 conv is bound by the matrix pipe (MFMA-busy 0.86, clock at the power wall: profiles/r03_sq_summary.md); what moves its time
+// is removing MFMAs.  Along x an output pair (X, X+1) of a k3 correlation needs the four inputs d0..d3 = in[X-1 .. X+2] and, per
+// (dz, dy, cin), SIX products; in Winograd's minimal form FOUR:
+//     t0 = d0 - d2   t1 = d1 + d2   t2 = d2 - d1   t3 = d1 - d3            (input transform: +-1 only)
+//     u0 = g0   u1 = (g0 + g1 + g2) / 2   u2 = (g0 - g1 + g2) / 2   u3 = g2 (weights: host, in double, before the fp16 split)
+//     m_f = sum over (dz, dy, cin) of t_f u_f                               (four GEMMs with K = 9 Cin instead of one with K = 27 Cin)
+//     out[X] = (m0 + m1) + m2       out[X+1] = (m1 - m2) - m3               (output transform: +-1 only)
+// The t_f are sums of two 22-bit values, formed in fp32 and split into an fp16 pair again exactly like a stored activation, so each
+// product keeps the fp16x3 precision; the error against fp64 grows ~1.3 x over the direct form and stays at fp32-conv level
+// (scripts/study/winograd_x_error.py).  y and z stay direct: each transformed axis doubles the accumulators, and 2 x is what fits.
+//
+// Workgroup = NG cout groups of four waves, ONE workgroup per CU (it holds 100 KB of LDS).  Block = 4 z x 8 y x 8 x outputs = 128
+// x pairs; wave w of a group owns frequency f = w: four 32-row tiles (one per z slice; row = 8 y x 4 pairs) x 64 couts = 128
+// accumulators, the same register shape as conv3_igemm_sres -- and the same tap loop, with 9 taps (dz, dy) per 16-channel chunk.
+//
+// Per chunk:  [transform: raw halo (LDS) -> T (LDS), one (z, y, pair, channel-half) unit per thread: 8 x 16 B in, ~180 VALU, 8 x 16 B out]
+//             [barrier] [9 taps: A fragments from T, weight fragments from L2, 24 MFMAs each; the raw halo of chunk c+1 arrives by
+//             LDS-DMA meanwhile, one piece per tap] [barrier].
+// The raw halo (6 x 10 x 10 records) is single-buffered: it is dead once transformed, i.e. before the taps start.  T holds the four
+// frequencies of the halo box: record (hz, f, hy, pair) at ((hz * 4 + f) * 10 + hy) * 4 + pair, slots XOR-swizzled by hy & 3 (16
+// lanes of an A-fragment read = 4 y x 4 pairs hit 16 different 16-byte bank groups).  The raw box is laid out for the transform's
+// reads, not as records: piece L = (hz * 10 + hy) * 41 + (term * 10 + hx) * 2 + half (one pad piece per row: 16 lanes = 4 y x 4 pairs
+// read 16 different bank groups); global_load_lds writes lane-linearly, so the permutation is applied to the SOURCE address.
+//
+// Epilogue: the four frequencies of an output sit in four waves.  Per cout half the waves of a group exchange accumulators through
+// LDS (wave w keeps z slice w: it sends three slices and receives three frequencies, 48 KB per group), apply the output transform,
+// scale / shift / ReLU / split as conv3_igemm_sres does, build the block's image in LDS and copy it out 16 B per lane.
+//
+// Every value of an output depends only on the parity of its x (pairs start at even tile coordinates: the host aligns the launch box)
+// -- not on the block grid, the batch or the launch box: results do not depend on how tiles are batched.
+#pragma once
+#include "unet_sres2.h"
+
+namespace oai {
+
+// Block shapes: TY rows x NP pairs with TY * NP = 32 -- 8 x 4 (the main shape, figures above), 4 x 8 (y remainders of <= 4 rows) and
+// 16 x 2 (x remainders of <= 4 columns): trimmed boxes are e.g. 12 x 52 x 52, and a block that is half outside its box costs all of its MFMAs.
+// MS = 2 (NG = 1, layers with ONE block of 64 couts): eight waves all the same, wave (zp, f) owns frequency f of the z slices 2 zp, 2 zp + 1
+// -- two accumulator tiles x 64 couts; the two waves of a frequency fetch the same weight fragments (the second from L1).  Four waves with
+// four tiles each (NG = 1, MS = 1) leave every SIMD with one wave: measured no faster than the direct kernel.
+template <int NG, int TY, int NP, int MS = 1>
+__global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+    constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
+    static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
+    constexpr int TZ = 4, TX = 2 * NP, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int RS = 4 * HX + 1;                                // 16-byte pieces per raw row (hz, hy): [term][hx][half] + 1 pad
+    constexpr int PIECES = HZ * HY * RS;                          // 2460 for 8 x 4
+    constexpr int NIT = (PIECES + NT - 1) / NT;                   // LDS-DMA instructions per thread per chunk: 5 (NG 2) / 10 (NG 1) for 8 x 4
+    constexpr int TB = HZ * 4 * HY * NP * 64;                     // 61 440 bytes of T for 8 x 4
+    constexpr int RAWB = NIT * NT * 16;                           // 40 960 bytes of raw box (whole 1-KiB wave writes)
+    constexpr int UNITS = HZ * 2 * HY * NP;                       // 480 transform units (hz, half, hy, pair)
+    constexpr int XB = 3 * 4 * 4 * 1024;                          // exchange buffer of one cout group: [f][3 slices][4 row groups][lane] x 16 B
+    static_assert(NG == 1 || NG == 2, "one or two cout groups");
+    static_assert(TY * NP == 32 && (NP == 2 || NP == 4 || NP == 8), "32 rows per accumulator tile");
+    static_assert(TB + RAWB <= 160 * 1024 && NG * MS * XB <= TB + RAWB && TZ * TY * TX * 128 <= XB && TZ * TY * TX * 256 <= TB + RAWB, "epilogue buffers live in the idle T / raw space");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TB + RAWB];
+    unsigned char* const Tl = lds;
+    unsigned char* const raw = lds + TB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = MS == 2 ? 0 : wave >> 2, zp = MS == 2 ? wave >> 2 : 0, f = wave & 3, gtid = tid & 255;
+    int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
+    if (id < 0) return;
+    const int cbg = id % a.ncb; id /= a.ncb;                      // a.ncb = Cout / (64 NG) for this kernel
+    const int bx = id % a.nbx; id /= a.nbx;
+    const int by = id % a.nby; id /= a.nby;
+    const int bz = id % a.nbz; id /= a.nbz;
+    const int tile = id;
+    const int cb = cbg * NG + grp;                                // this group's block of 64 couts
+    const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * TY, ox0 = a.lo[2] + bx * TX;      // a.lo[2] is even (host)
+    int blo[3], bhi[3];
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + TY <= blo[1] || ox0 >= bhi[2] || ox0 + TX <= blo[2]) return;
+
+    const int row = lane & 31, half = lane >> 5;
+    const int yl = row / NP, pr = row % NP;                       // this lane's A row: y, x pair
+    const int m_lo = max(0, blo[0] - oz0), m_hi = min(TZ, bhi[0] - oz0);
+
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+    const unsigned char* s0 = reinterpret_cast<const unsigned char*>(a.src0) + srec(tile, nch0, plane, 0, 0);
+    const unsigned char* s1 = reinterpret_cast<const unsigned char*>(a.src1) + srec(tile, nch1, plane, 0, 0);
+
+    // ---- staging plan: piece L = it * NT + tid of the raw box -> byte offset of its 16 bytes inside a chunk plane, or kNoPiece (outside
+    // the tile = Conv3d's zero padding, pad piece, beyond the box) -> the zero record
+    constexpr unsigned kNoPiece = 0xFFFFFFFFu;
+    unsigned poff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int L = it * NT + tid;
+        const int rw = L / RS, c = L - rw * RS;
+        const int hz = rw / HY, hy = rw - hz * HY;
+        const int term = c / (2 * HX), hx = (c - term * 2 * HX) >> 1, hf = c & 1;
+        const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+        const bool ok = L < PIECES && c < 4 * HX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        poff[it] = ok ? ((unsigned)((gz * a.H + gy) * a.W + gx) << 6) | (unsigned)(term * 32 + hf * 16) : kNoPiece;
+    }
+    const unsigned raw0 = lds_addr_of(raw);
+    // one piece of chunk `ch`; past the last chunk the zero record is fetched instead, so that every chunk issues the same number of
+    // vector-memory operations (the counted waits below depend on it)
+    auto issue_piece = [&](int it, int ch) __attribute__((always_inline)) {
+        const bool real = ch < nchunks;
+        const bool first = ch < nch0;
+        const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
+        const unsigned char* g = (real && poff[it] != kNoPiece) ? cbase + poff[it] : zero_rec;
+        lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16));
+    };
+    // pieces requested in tap t (for the NEXT chunk): spread over the nine taps, the early taps take the remainder
+    auto pieces_in_tap = [](int t) constexpr { return NIT / 9 + (t < NIT % 9 ? 1 : 0); };
+    auto first_piece = [](int t) constexpr { return t * (NIT / 9) + (t < NIT % 9 ? t : NIT % 9); };
+    static_assert(NIT <= 18, "at most two pieces per tap (vm_wait<0..2>)");
+
+    // ---- input transform of the staged chunk: raw -> T
+    float tmax = 0.0f;                                            // max |t|: a t beyond fp16's range must raise the overflow flag (inputs <= 65504, t <= 131008)
+    auto transform = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ui = 0; ui < (UNITS + NT - 1) / NT; ++ui) {
+            const int u = ui * NT + tid;
+            if (u < UNITS) {
+                const int p = u % NP;
+                int t = u / NP;
+                const int hy = t % HY; t /= HY;
+                const int hf = t & 1, hz = t >> 1;
+                const unsigned char* rb = raw + (((hz * HY + hy) * RS) + 4 * p + hf) * 16;
+                float x[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u16x8 h0 = *reinterpret_cast<const u16x8*>(rb + (2 * i) * 16);
+                    const u16x8 h1 = *reinterpret_cast<const u16x8*>(rb + (2 * HX + 2 * i) * 16);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) x[i][c] = join2_f16(h0[c], h1[c]);
+                }
+                unsigned char* tw = Tl + (((hz * 4) * HY + hy) * NP + p) * 64;
+                const int key = ((hy * NP + p) >> 2) & 3;
+                const int sl0 = ((hf) ^ key) * 16, sl1 = ((2 + hf) ^ key) * 16;
+#pragma unroll
+                for (int fq = 0; fq < 4; ++fq) {
+                    u16x8 hi, lo;
+#pragma unroll
+                    for (int c = 0; c < 8; c += 2) {
+                        f32x2 v;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            v[e] = fq == 0 ? x[0][c + e] - x[2][c + e] : fq == 1 ? x[1][c + e] + x[2][c + e] : fq == 2 ? x[2][c + e] - x[1][c + e] : x[1][c + e] - x[3][c + e];
+                        tmax = fmaxf(tmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                        const f16x2 h = __builtin_convertvector(v, f16x2);
+                        const f32x2 res = v - __builtin_convertvector(h, f32x2);
+                        const f16x2 l = __builtin_convertvector(res, f16x2);
+                        const unsigned H = __builtin_bit_cast(unsigned, h), Lw = __builtin_bit_cast(unsigned, l);
+                        hi[c] = (unsigned short)H; hi[c + 1] = (unsigned short)(H >> 16);
+                        lo[c] = (unsigned short)Lw; lo[c + 1] = (unsigned short)(Lw >> 16);
+                    }
+                    *reinterpret_cast<u16x8*>(tw + fq * (HY * NP * 64) + sl0) = hi;
+                    *reinterpret_cast<u16x8*>(tw + fq * (HY * NP * 64) + sl1) = lo;
+                }
+            }
+        }
+    };
+
+    // ---- A fragments: this lane's record for tap (dz, dy) = (0, 0), slice 0, and its swizzled slot per dy and term
+    const int aofs = (((zp * MREP * 4 + f) * HY + yl) * NP + pr) * 64;
+    int sl[3][2];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) sl[dy][t] = ((t * 2 + half) ^ (((row + dy * NP) >> 2) & 3)) * 16;
+
+    constexpr int STEP = 2 * NREP * 64;                             // 16-byte units of weights per tap: [term][nr][lane]
+    // panel of pack_wino_panel: [cb][f][chunk][tap 9][term][nr][lane]; wave-uniform base, forced into an SGPR pair
+    const size_t wp_v = (size_t)(a.wpanel + (size_t)(cb * 4 + f) * nchunks * 9 * STEP);
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(
+        ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wp_v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp_v));
+    const unsigned wlane = lane * 16;
+
+    // ---- prologue: the first raw box and the weight fragments of tap 0
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) issue_piece(it, 0);
+    f32x4 bq[2][2][NREP];                                           // [tap parity][term][n]
+    sgpr_settle(wp);                                                // wp has just been made uniform by v_readfirstlane
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bq[0][k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
+                                                            : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+    wp += STEP * 16;
+    static_assert(NREP == 2, "vm_wait names four fragments");
+    vm_wait<0>(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+    __syncthreads();
+
+    auto run_chunks = [&](auto ml_tag) __attribute__((always_inline)) {
+        constexpr int ML = decltype(ml_tag)::value;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            transform();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // T is complete; the raw box is free for the next chunk's pieces
+            asm volatile("" ::: "memory");
+            const unsigned char* abase = Tl + aofs;
+            auto load_a = [&](float4 (&dst)[MREP], int t, int k) __attribute__((always_inline)) {
+                const int dz = t / 3, dy = t % 3;
+#pragma unroll
+                for (int m = 0; m < ML; ++m)
+                    dst[m] = *reinterpret_cast<const float4*>(abase + (((m + dz) * 4 * HY + dy) * NP) * 64 + sl[dy][k]);      // (abase: slice zp * MREP)
+            };
+            float4 acur[2][MREP];
+            load_a(acur[0], 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x4 (&bc)[2][NREP] = bq[t & 1];
+                f32x4 (&bn)[2][NREP] = bq[(t + 1) & 1];
+                // B(t) was requested in tap t-1, in front of that tap's pieces: they may stay in flight
+                {
+                    constexpr int kDummy = 0; (void)kDummy;
+                    const int younger = t > 0 ? pieces_in_tap(t - 1) : 0;
+                    if (younger == 0) vm_wait<0>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
+                    else if (younger == 1) vm_wait<1>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
+                    else vm_wait<2>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
+                }
+                load_a(acur[1], t, 1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n)
+                        bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
+                                          : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+                wp += STEP * 16;
+#pragma unroll
+                for (int q = 0; q < pieces_in_tap(t); ++q) issue_piece(first_piece(t) + q, ch + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)                              // a0.b0, a0.b1
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[0][m], __builtin_bit_cast(float4, bc[p][n]), acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < 9) load_a(acur[0], t + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < ML; ++m)                             // a1.b0
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[1][m], __builtin_bit_cast(float4, bc[0][n]), acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // 9 is odd: the fragments of the next chunk's tap 0 are in bq[1]; the wait also covers every piece of the next raw box (older):
+            // it has landed for this thread, the barrier says so for everybody -- and that everybody is done reading T
+            vm_wait<0>(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) bq[0][k][n] = bq[1][k][n];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
+    const int mlb = m_lo == 0 ? m_hi : TZ;                          // live z slices of the block (workgroup-uniform) ...
+    const int ml = min(MREP, max(0, mlb - zp * MREP));              // ... and of this wave (wave-uniform; MS = 2: the upper pair of a 1- or 2-slice block idles through the taps)
+    if constexpr (MS == 1) {
+        if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
+        else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
+        else if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+        else run_chunks(std::integral_constant<int, 1>{});
+    } else {
+        if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+        else if (ml == 1) run_chunks(std::integral_constant<int, 1>{});
+        else run_chunks(std::integral_constant<int, 0>{});
+    }
+    if (tmax > 65504.0f) atomicOr(a.range_flag, 1);
+
+    // ---- epilogue
+    constexpr int TV = TZ * TY * TX;                                // 256 voxels
+    constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
+    unsigned char* const xb = lds + grp * XB;                       // exchange buffer, then output image, of this group
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+    const int nco = (a.Cout + 15) / 16;
+    float vmax = 0.0f;
+    float scv[NREP], shv[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = cb * 64 + n * 32 + row;
+        scv[n] = co < a.Cout ? a.scale[co] : 0.0f; shv[n] = co < a.Cout ? a.shift[co] : 0.0f;
+    }
+    asm volatile("" : "+v"(scv[0]), "+v"(scv[1]), "+v"(shv[0]), "+v"(shv[1]));
+    int clo[3], chi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { clo[i] = blo[i]; chi[i] = bhi[i]; }
+    if (a.store_boxes) {
+        const int* sb = a.store_boxes + 6 * tile;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { clo[i] = max(clo[i], sb[i] - a.store_grow); chi[i] = min(chi[i], sb[3 + i] + a.store_grow); }
+    }
+    // wave F (= frequency F during the taps) finishes z slice F
+    auto finish = [&](auto ftag) __attribute__((always_inline)) {
+        constexpr int F = decltype(ftag)::value;
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int co = cb * 64 + n * 32 + row;
+            const bool cvalid = co < nco * 16;
+            const float sc = scv[n], sh = shv[n];
+            __syncthreads();                                          // T reads / the previous half's copy-out are done
+            // send: slice m of frequency F to wave m
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                if (m == F) continue;
+                constexpr int kDummy = 0; (void)kDummy;
+                const int slot = F * 3 + (m > F ? m - 1 : m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = {acc[m][n][4 * j], acc[m][n][4 * j + 1], acc[m][n][4 * j + 2], acc[m][n][4 * j + 3]};
+                    *reinterpret_cast<f32x4*>(xb + ((slot * 4 + j) * 64 + lane) * 16) = v;
+                }
+            }
+            __syncthreads();
+            // receive: slice F of the other three frequencies
+            float M[4][16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g == F) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) M[g][r] = acc[F][n][r];
+                } else {
+                    const int slot = g * 3 + (F > g ? F - 1 : F);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((slot * 4 + j) * 64 + lane) * 16);
+                        M[g][4 * j] = v[0]; M[g][4 * j + 1] = v[1]; M[g][4 * j + 2] = v[2]; M[g][4 * j + 3] = v[3];
+                    }
+                }
+            }
+            __syncthreads();                                          // everybody has its frequencies: the buffer becomes the output image
+            const bool odd = row & 1;
+            const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+            unsigned char* lrow = xb + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
+            const int oz = oz0 + F;
+            const bool zok = oz >= blo[0] && oz < bhi[0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;      // C/D row of register r
+                const int ty = rr / NP, tx = 2 * (rr % NP);
+                const float y0 = (M[0][r] + M[1][r]) + M[2][r];
+                const float y1 = (M[1][r] - M[2][r]) - M[3][r];
+                float v[2] = {y0 * sc + sh, y1 * sc + sh};
+                const int oy = oy0 + ty;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (a.relu) v[e] = fmaxf(v[e], 0.0f);
+                    const int ox = ox0 + tx + e;
+                    const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
+                    v[e] = ok ? v[e] : 0.0f;                           // voxels outside the box are never copied out
+                }
+                vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                unsigned w_hi, w_lo;
+                split_two_voxels(v[0], v[1], sel, w_hi, w_lo);
+                const int vox = (F * TY + ty) * TX + tx + (odd ? 1 : 0);
+                unsigned char* dst = lrow + vox * 128;
+                *reinterpret_cast<unsigned*>(dst) = w_hi;
+                *reinterpret_cast<unsigned*>(dst + 32) = w_lo;
+            }
+            __syncthreads();
+            {
+                const int t5 = gtid >> 3, q = gtid & 7;
+                const int x_lane = t5 % TX, y_lane = t5 / TX;
+                const bool cok = cb * 4 + n * 2 + (q >> 2) < nco;
+                unsigned char* ob = outb + ((size_t)tile * nco + cb * 4 + n * 2) * plane * 64;                        // wave-uniform
+                const unsigned lane_off = (unsigned)(((size_t)(q >> 2) * plane + (size_t)y_lane * a.W + x_lane) * 64 + (q & 3) * 16);
+                const int oyl = oy0 + y_lane, oxl = ox0 + x_lane;
+#pragma unroll
+                for (int it = 0; it < EIT; ++it) {
+                    const int zc = it >> 1, yc = (it & 1) * (32 / TX);
+                    const int ozc = oz0 + zc, oy = oyl + yc;
+                    if (cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
+                        const unsigned uni = (unsigned)(((ozc * a.H + oy0 + yc) * a.W + ox0) * 64);                  // wave-uniform
+                        float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
+                        const float4 val = *reinterpret_cast<const float4*>(xb + (it * 256 + gtid) * 16);
+                        __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                        __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                    }
+                }
+            }
+        }
+    };
+    // MS = 2: wave (zp, F) holds frequency F of the units e = (local slice s, cout half n) = 2 s + n of its slice pair; it finishes unit F.
+    // One exchange (48 KB per slice pair), then ONE image of the whole block, 256 B per voxel (four 16-cout records), copied out by all 512 threads.
+    auto finish2 = [&](auto ftag) __attribute__((always_inline)) {
+        constexpr int F = decltype(ftag)::value;
+        constexpr int S = F >> 1, N = F & 1;
+        unsigned char* const xz = lds + zp * XB;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e == F) continue;
+            constexpr int kDummy = 0; (void)kDummy;
+            const int slot = F * 3 + (e > F ? e - 1 : e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = {acc[e >> 1][e & 1][4 * j], acc[e >> 1][e & 1][4 * j + 1], acc[e >> 1][e & 1][4 * j + 2], acc[e >> 1][e & 1][4 * j + 3]};
+                *reinterpret_cast<f32x4*>(xz + ((slot * 4 + j) * 64 + lane) * 16) = v;
+            }
+        }
+        __syncthreads();
+        float M[4][16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g == F) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) M[g][r] = acc[S][N][r];
+            } else {
+                const int slot = g * 3 + (F > g ? F - 1 : F);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xz + ((slot * 4 + j) * 64 + lane) * 16);
+                    M[g][4 * j] = v[0]; M[g][4 * j + 1] = v[1]; M[g][4 * j + 2] = v[2]; M[g][4 * j + 3] = v[3];
+                }
+            }
+        }
+        __syncthreads();                                              // both slice pairs have their frequencies: the buffers become the output image
+        const int co = cb * 64 + N * 32 + row;
+        const bool cvalid = co < nco * 16;
+        const float sc = scv[N], sh = shv[N];
+        const bool odd = row & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+        unsigned char* lrow = lds + (N * 2 + (row >> 4)) * 64 + ((row & 15) >> 1) * 4;
+        const int zs = zp * 2 + S;
+        const int oz = oz0 + zs;
+        const bool zok = oz >= blo[0] && oz < bhi[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int ty = rr / NP, tx = 2 * (rr % NP);
+            const float y0 = (M[0][r] + M[1][r]) + M[2][r];
+            const float y1 = (M[1][r] - M[2][r]) - M[3][r];
+            float v[2] = {y0 * sc + sh, y1 * sc + sh};
+            const int oy = oy0 + ty;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (a.relu) v[e] = fmaxf(v[e], 0.0f);
+                const int ox = ox0 + tx + e;
+                const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
+                v[e] = ok ? v[e] : 0.0f;
+            }
+            vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+            unsigned w_hi, w_lo;
+            split_two_voxels(v[0], v[1], sel, w_hi, w_lo);
+            const int vox = (zs * TY + ty) * TX + tx + (odd ? 1 : 0);
+            unsigned char* dst = lrow + vox * 256;
+            *reinterpret_cast<unsigned*>(dst) = w_hi;
+            *reinterpret_cast<unsigned*>(dst + 32) = w_lo;
+        }
+        __syncthreads();
+        {
+            const int t6 = tid >> 4, q = tid & 15;
+            const int x_lane = t6 % TX, y_lane = t6 / TX;
+            const bool cok = cb * 4 + (q >> 2) < nco;
+            unsigned char* ob = outb + ((size_t)tile * nco + cb * 4) * plane * 64;                                    // wave-uniform
+            const unsigned lane_off = (unsigned)(((size_t)(q >> 2) * plane + (size_t)y_lane * a.W + x_lane) * 64 + (q & 3) * 16);   // 4 * plane * 64 < 2^32 (host check)
+            const int oyl = oy0 + y_lane, oxl = ox0 + x_lane;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int zc = it >> 1, yc = (it & 1) * (32 / TX);
+                const int ozc = oz0 + zc, oy = oyl + yc;
+                if (cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
+                    const unsigned uni = (unsigned)(((ozc * a.H + oy0 + yc) * a.W + ox0) * 64);                      // wave-uniform
+                    float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
+                    const float4 val = *reinterpret_cast<const float4*>(lds + (it * 512 + tid) * 16);
+                    __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                    __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                }
+            }
+        }
+    };
+    if constexpr (MS == 1) {
+        if (f == 0) finish(std::integral_constant<int, 0>{});
+        else if (f == 1) finish(std::integral_constant<int, 1>{});
+        else if (f == 2) finish(std::integral_constant<int, 2>{});
+        else finish(std::integral_constant<int, 3>{});
+    } else {
+        if (f == 0) finish2(std::integral_constant<int, 0>{});
+        else if (f == 1) finish2(std::integral_constant<int, 1>{});
+        else if (f == 2) finish2(std::integral_constant<int, 2>{});
+        else finish2(std::integral_constant<int, 3>{});
+    }
+    census_note(a.census, a.range_flag, vmax);
+}
+
+}  // namespace oai

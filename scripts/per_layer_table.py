@@ -22,10 +22,10 @@ if len(rows) > 1 and "pooled_gather" in rows[1]["Kernel_Name"]:
     rows = rows[k + 1:]
 for r in rows:
     n = r["Kernel_Name"]
-    main = "conv3_igemm_sres<4, 16, 2, 4, 1" in n or "conv3_igemm_sres2<16, 2, 4, 1" in n
+    main = "conv3_igemm_sres<4, 16, 2, 4, 1" in n or "conv3_igemm_sres2<16, 2, 4, 1" in n or ("conv3_wino_sres<" in n and ", 8, 4" in n)
     if "conv3_first" in n and not fused: layers.append(["ec0", dur(r), 1]); continue
     if "upconv2" in n or main: layers.append([None, dur(r), 1]); cur = layers[-1]; continue
-    if "conv3_igemm_sres" in n and cur is not None: cur[1] += dur(r); cur[2] += 1; continue      # strip launches belong to the layer before them
+    if ("conv3_igemm_sres" in n or "conv3_wino_sres" in n) and cur is not None: cur[1] += dur(r); cur[2] += 1; continue      # strip launches belong to the layer before them
     layers.append([n[:40], dur(r), 1])
 names = iter(ORDER)
 print("| layer | launches | us (160 tiles) | algorithmic TFLOP (160 tiles) | TFLOP/s | of 2.5 PFLOP/s |")
