@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
     static_assert(NIT <= 18, "at most two pieces per tap (vm_wait<0..2>)");
 
     // ---- input transform of the staged chunk: raw -> T
-    float tmax = 0.0f;                                            // max |t|: a t beyond fp16's range must raise the overflow flag (inputs <= 65504, t <= 131008)
+    // (a t beyond fp16's range -- inputs <= 65504, |t| <= 131008 -- becomes the pair (inf, -inf): every output that depends on it turns NaN and
+    // is reported by the epilogue's finiteness test.  Not tested here: halo voxels that no output inside the box reads may be uninitialised memory.)
     auto transform = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ui = 0; ui < (UNITS + NT - 1) / NT; ++ui) {
@@ -152,7 +153,6 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
 #pragma unroll
                         for (int e = 0; e < 2; ++e)
                             v[e] = fq == 0 ? x[0][c + e] - x[2][c + e] : fq == 1 ? x[1][c + e] + x[2][c + e] : fq == 2 ? x[2][c + e] - x[1][c + e] : x[1][c + e] - x[3][c + e];
-                        tmax = fmaxf(tmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
                         const f16x2 h = __builtin_convertvector(v, f16x2);
                         const f32x2 res = v - __builtin_convertvector(h, f32x2);
                         const f16x2 l = __builtin_convertvector(res, f16x2);
@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
         else if (ml == 1) run_chunks(std::integral_constant<int, 1>{});
         else run_chunks(std::integral_constant<int, 0>{});
     }
-    if (tmax > 65504.0f) atomicOr(a.range_flag, 1);
 
     // ---- epilogue
     constexpr int TV = TZ * TY * TX;                                // 256 voxels
@@ -284,6 +283,7 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int nco = (a.Cout + 15) / 16;
     float vmax = 0.0f;
+    bool nonfinite = false;                                         // an output inside the box that is inf / NaN (an overflowed t): fmaxf would drop the NaN silently
     float scv[NREP], shv[NREP];
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
@@ -353,9 +353,10 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
                 const int oy = oy0 + ty;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    if (a.relu) v[e] = fmaxf(v[e], 0.0f);
                     const int ox = ox0 + tx + e;
                     const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
+                    nonfinite |= ok && !(fabsf(v[e]) <= 3.0e38f);      // (before the ReLU: fmaxf(NaN, 0) = 0)
+                    if (a.relu) v[e] = fmaxf(v[e], 0.0f);
                     v[e] = ok ? v[e] : 0.0f;                           // voxels outside the box are never copied out
                 }
                 vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
@@ -443,9 +444,10 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
             const int oy = oy0 + ty;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                if (a.relu) v[e] = fmaxf(v[e], 0.0f);
                 const int ox = ox0 + tx + e;
                 const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
+                nonfinite |= ok && !(fabsf(v[e]) <= 3.0e38f);      // (before the ReLU: fmaxf(NaN, 0) = 0)
+                if (a.relu) v[e] = fmaxf(v[e], 0.0f);
                 v[e] = ok ? v[e] : 0.0f;
             }
             vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
@@ -489,6 +491,7 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
         else if (f == 2) finish2(std::integral_constant<int, 2>{});
         else finish2(std::integral_constant<int, 3>{});
     }
+    if (nonfinite) atomicOr(a.range_flag, 1);
     census_note(a.census, a.range_flag, vmax);
 }
 
