@@ -33,7 +33,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense 16-bit MFMA
 PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}
 SUSTAINED_16BIT_MFMA_TFLOPS = 1857.0   # scripts/micro/mfma_peak.hip on this chip: operands in registers, every CU (profiles/r01_ablation.md)
-KERNEL_OF = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_igemm_sres (split-resident fp16x3)",
+KERNEL_OF = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_wino_sres / conv3_igemm_sres (split-resident fp16x3; x axis of the plain layers in Winograd F(2,3) form)",
              "bf16x3": "conv3_igemm_bf16s (split 16-bit)", "bf16x6": "conv3_igemm_bf16s (split 16-bit)"}
 DTYPE_OF = {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
             "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
@@ -457,6 +457,10 @@ def main():
                     "achieved_frame_aware": ach_fa, "frac_frame_aware": ach_fa / peak,
                     "mfma_passes_per_product": PASSES[prec], "executed_frac": ach_fa * PASSES[prec] / peak,
                     "executed_frac_of_sustained_issue_rate": None if prec == "f32" else ach_fa * PASSES[prec] / SUSTAINED_16BIT_MFMA_TFLOPS,
+                    "executed_note": None if prec == "f32" else
+                    "executed_frac counts 3 MFMA passes per ALGORITHMIC product; the plain k3 layers (ec2 ec4 ec6 ec7 dc8 dc7 dc5 dc4 dc2, 73 % of the "
+                    "3x3x3 algorithmic FLOP) run the x axis in Winograd F(2,3) form and execute 2/3 of that (unet_wino.h, profiles/r03_winograd.md): for them "
+                    "it overstates the matrix pipe's load, `frac` (algorithmic FLOP / time / peak) is the contract figure",
                     "algorithmic_flops_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                     "clock_note": None if prec == "f32" else
                     "the 16-bit MFMA path is power-limited on this workload: sclk 1.96 GHz at ~1.28 kW (profiles/r01_power.md), i.e. a "

@@ -226,7 +226,7 @@ static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int 
 static std::vector<float> pack_wino_panel(const std::vector<float>& wk, int C0, int C1, int Cout, const std::vector<float>& wscale, float src1_factor) {
     const int Cin = C0 + C1, KC = 16;
     const int ncb = Cout / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
-    const size_t units = ((size_t)ncb * 4 * (nch0 + nch1) * 9 + 1) * 2 * 2 * 64;      // 16-byte units, +1 tap of prefetch slack
+    const size_t units = ((size_t)ncb * 4 * (nch0 + nch1) * 9 + 2) * 2 * 2 * 64;      // 16-byte units, +2 taps of prefetch slack (one is read)
     std::vector<float> out(units * 4, 0.0f);
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
     size_t u = 0;

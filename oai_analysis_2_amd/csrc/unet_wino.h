@@ -200,7 +200,9 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
     auto run_chunks = [&](auto ml_tag) __attribute__((always_inline)) {
         constexpr int ML = decltype(ml_tag)::value;
         for (int ch = 0; ch < nchunks; ++ch) {
-            transform();
+            // (-DOAI_DIAG builds, OAI_DBG bits -- timing only, results wrong: 4096 no weight-fragment loads in the taps, 8192 A fragments of tap 0 for
+            // every tap, 16384 transform of chunk 0 only, 32768 no DMA pieces in the taps; scripts/wino_var.sh, profiles/r03_winograd.md)
+            if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                            // T is complete; the raw box is free for the next chunk's pieces
             asm volatile("" ::: "memory");
@@ -225,16 +227,20 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
                     else if (younger == 1) vm_wait<1>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
                     else vm_wait<2>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
                 }
-                load_a(acur[1], t, 1);
+                if (!OAI_DBG_BIT(a, 8192) || t == 0) load_a(acur[1], t, 1);
+                if (!OAI_DBG_BIT(a, 4096)) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
+                    for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int n = 0; n < NREP; ++n)
-                        bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
-                                          : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+                        for (int n = 0; n < NREP; ++n)
+                            bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
+                                              : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+                }
                 wp += STEP * 16;
+                if (!OAI_DBG_BIT(a, 32768)) {
 #pragma unroll
-                for (int q = 0; q < pieces_in_tap(t); ++q) issue_piece(first_piece(t) + q, ch + 1);
+                    for (int q = 0; q < pieces_in_tap(t); ++q) issue_piece(first_piece(t) + q, ch + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < 2; ++p)                              // a0.b0, a0.b1
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[0][m], __builtin_bit_cast(float4, bc[p][n]), acc[m][n]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < 9) load_a(acur[0], t + 1, 0);
+                if (t + 1 < 9 && !OAI_DBG_BIT(a, 8192)) load_a(acur[0], t + 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < ML; ++m)                             // a1.b0

@@ -52,9 +52,9 @@ for a, b in zip(f, w):
     name = a["Kernel_Name"][:64]
     lines.append(f"| {name} | {fk:.0f} | {2*fk:.0f} | {wk:.0f} |")
     tot["all_f"] += 2 * fk; tot["all_w"] += wk
-    if "conv3_igemm_sres" in name: tot["conv_f"] += 2 * fk; tot["conv_w"] += wk; tot["conv_n"] += 1
+    if "conv3_igemm_sres" in name or "conv3_wino_sres" in name: tot["conv_f"] += 2 * fk; tot["conv_w"] += wk; tot["conv_n"] += 1
 open(O + "/traffic_table.md", "w").write("\n".join(lines) + "\n")
-js = {"kernel": "conv3_igemm_sres / conv3_igemm_sres2 (all tile shapes)", "bytes_per_launch": (tot["conv_f"] + tot["conv_w"]) * 2**20 / max(tot["conv_n"], 1),
+js = {"kernel": "conv3_igemm_sres / conv3_igemm_sres2 / conv3_wino_sres (all tile shapes)", "bytes_per_launch": (tot["conv_f"] + tot["conv_w"]) * 2**20 / max(tot["conv_n"], 1),
       "tiles_per_pass": int(os.environ.get("TILES", "160")),
       "fetch_x2_bytes_per_pass": tot["conv_f"] * 2**20, "write_bytes_per_pass": tot["conv_w"] * 2**20,
       "launches_per_pass": tot["conv_n"], "all_kernels_fetch_x2_bytes": tot["all_f"] * 2**20, "all_kernels_write_bytes": tot["all_w"] * 2**20}
@@ -70,7 +70,7 @@ if kt:
     for r in csv.DictReader(open(kt)):
         dur[r["Kernel_Name"][:60]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 with open(O + "/sq_summary.md", "w") as fo:
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:6]:
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:9]:
         t = dur.get(k, 0.0)
         clk = v.get("GRBM_GUI_ACTIVE", 0) / 8 / t / 1e9 if t else 0
         simd_cycles = clk * 1e9 * t * 1024
