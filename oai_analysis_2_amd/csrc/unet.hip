@@ -670,6 +670,14 @@ static int launch_conv3_wino(const oai_unet* h, const Layer& L, const ConvArgs& 
     return OAI_OK;
 }
 
+// the fused max-pool of conv3_wino_sres pools whole 2 x 2 x 2 windows of a block's own image: the box must be the whole (even-sized) tile
+// level, so that every block (any shape) starts at even coordinates and lies inside it
+static bool wino_pool_box(const Box& box, const int dims[3]) {
+    for (int i = 0; i < 3; ++i)
+        if (box.lo[i] != 0 || box.hi[i] != dims[i] || (dims[i] & 1)) return false;
+    return dims[0] % 4 == 0 && dims[1] % 8 == 0 && dims[2] % 8 == 0;      // main blocks only: no strips
+}
+
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
                         const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
                         float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr,
@@ -677,8 +685,8 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     ConvArgs a;
     if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
-    if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.pool_out && !a.sc_boxes &&
-        a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
+    if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.sc_boxes &&
+        (!a.pool_out || (a.Cout % 128 == 0 && wino_pool_box(box, dims))) && a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
         return launch_conv3_wino(h, L, a, box, ntiles, st);
     int ny, nx, hr, wr;
     strip_plan(h, box, ny, nx, hr, wr);

@@ -394,6 +394,38 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
                     }
                 }
             }
+            if constexpr (TY == 8 && NP == 4) if (a.pool_out) {       // (main shape only: the host asks for it where the box is whole blocks of it)
+                // MaxPool3d(2) fused (ec3 / ec5; networks.py:117,122), from the block's image: thread = (pooled voxel, 4 channels of one of the two
+                // 16-channel records); the pooled record keeps the (h0, h1) PAIR of the window's largest joined value -- the rule of
+                // maxpool2_sres_kernel (on equal values the pair with the larger h0: what splitting the fp32 maximum would have produced).
+                // Block origins are even (host) and blocks lie inside the tile: every window is whole.
+                static_assert(TZ * TY * TX / 8 == 32, "32 pooled voxels x 8 quarter records = the 256 threads of a cout group");
+                const int pv = gtid >> 3, q = gtid & 7;
+                const int px = pv % (TX / 2), py = (pv / (TX / 2)) % (TY / 2), pz = pv / ((TX / 2) * (TY / 2));
+                float mval[4];
+                u16x4 mh, ml;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int vox = ((2 * pz + (k >> 2)) * TY + 2 * py + ((k >> 1) & 1)) * TX + 2 * px + (k & 1);
+                    const unsigned char* rec = xb + vox * 128 + (q >> 2) * 64 + (q & 3) * 8;
+                    const u16x4 h = *reinterpret_cast<const u16x4*>(rec), l = *reinterpret_cast<const u16x4*>(rec + 32);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = join2_f16(h[j], l[j]);
+                        const bool better = k == 0 || v > mval[j] ||
+                                            (v == mval[j] && (float)__builtin_bit_cast(_Float16, h[j]) > (float)__builtin_bit_cast(_Float16, mh[j]));
+                        if (better) { mval[j] = v; mh[j] = h[j]; ml[j] = l[j]; }
+                    }
+                }
+                const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
+                const int gz = oz0 / 2 + pz, gy = oy0 / 2 + py, gx = ox0 / 2 + px;
+                if (cb * 4 + n * 2 + (q >> 2) < nco && gz < Dp && gy < Hp && gx < Wp) {
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(a.pool_out) +
+                                         srec(tile, nco, (size_t)Dp * Hp * Wp, cb * 4 + n * 2 + (q >> 2), ((size_t)gz * Hp + gy) * Wp + gx) + (q & 3) * 8;
+                    *reinterpret_cast<u16x4*>(dst) = mh;
+                    *reinterpret_cast<u16x4*>(dst + 32) = ml;
+                }
+            }
         }
     };
     // MS = 2: wave (zp, F) holds frequency F of the units e = (local slice s, cout half n) = 2 s + n of its slice pair; it finishes unit F.
