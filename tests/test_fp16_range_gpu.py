@@ -156,3 +156,34 @@ def test_rescaled_network_full_volume_vs_reference_golden(golden_dir):
     print(f"[fullsize rescaled fp16x3] mask flips vs the reference: {len(flips)} of {2 * n}; max |p_ref - 0.5| at a flip = {max(dist_, default=0.0):.2e}; "
           f"exponents {eng.act_exponents()[0]}")
     assert all(d < 1e-5 for d in dist_) and len(flips) <= 64
+
+
+def test_an_overflowing_transformed_input_of_the_winograd_form_raises_the_flag():
+    """conv3_wino_sres feeds the matrix pipe t = d1 + d2 (and differences) of x-neighbouring activations, re-split into an fp16 pair: stored
+    activations in (32752, 65504] are legal, their sum is not.  Such a t becomes (inf, -inf), its outputs NaN -- which fmaxf / ReLU would turn
+    into 0 silently; the kernel tests the finiteness of every output inside the box BEFORE the ReLU and raises the overflow bit.
+    Deterministic scene: positive weights, no bias, constant input -> every activation is constant and maximal in the interior of its tensor,
+    so the largest stored value has an equal x neighbour.  ec3's exponent is then raised until its maximum sits just below fp16's limit: the
+    direct form stays clean, the Winograd form (ec4 reads the pooled ec3) must flag."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = make_unet_state_dict(seed=11, bias=False)
+    sd = {k: (v.abs() if k.endswith(".0.weight") else v) for k, v in sd.items()}
+    x = torch.full((1, 1, 32, 64, 64), 0.7)
+    EC3, bit = 3, 1
+    flags = {}
+    for wino in (0, 3):
+        eng = UNetEngine(sd, precision="fp16x3")
+        eng.set_option("winograd", wino)
+        eng.forward_tiles(x)                                   # calibrates: every layer's maximum in [2^10, 2^11) (and leaves the census empty)
+        eng.forward_tiles(x)
+        mx = eng.census()[EC3]                                 # (before range_flag(): evaluating the flag clears the census)
+        assert 1024.0 <= mx < 2048.0 and eng.range_flag() == 0
+        e, _ = eng.act_exponents()
+        e = list(e)
+        e[EC3] += int(np.floor(np.log2(65504.0 / mx)))          # stored maximum now in (32752, 65504]
+        eng.set_act_exponents(e)
+        eng.forward_tiles(x)
+        assert 32752.0 < eng.census()[EC3] <= 65504.0
+        flags[wino] = eng.range_flag()
+    assert flags[0] & bit == 0, "the direct form has nothing to report: every stored activation fits fp16"
+    assert flags[3] & bit == bit, "an overflowing Winograd input must raise the overflow bit"
