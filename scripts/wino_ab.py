@@ -15,6 +15,7 @@ def run(reps=3):
         b = eng.segment_tiles(vol, tile, ovl, None, 0, 160, ovl)
         torch.cuda.synchronize(); ts.append(time.time() - t)
     return min(ts), eng.stitch(b, vol.shape, tile, ovl, ovl)
+eng.set_option("winograd", 0)                         # (the default is 3)
 t0, base = run()
 print(f"winograd 0: {t0 * 1e3:.1f} ms   flag {eng.range_flag()}")
 for w in [int(v) for v in os.environ.get("WINO", "1,3").split(",")]:
