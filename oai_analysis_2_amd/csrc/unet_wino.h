@@ -19,14 +19,19 @@
 //             [barrier] [9 taps: A fragments from T, weight fragments from L2, 24 MFMAs each; the raw halo of chunk c+1 arrives by
 //             LDS-DMA meanwhile, one piece per tap] [barrier].
 // The raw halo (6 x 10 x 10 records) is single-buffered: it is dead once transformed, i.e. before the taps start.  T holds the four
-// frequencies of the halo box: record (hz, f, hy, pair) at ((hz * 4 + f) * 10 + hy) * 4 + pair, slots XOR-swizzled by hy & 3 (16
-// lanes of an A-fragment read = 4 y x 4 pairs hit 16 different 16-byte bank groups).  The raw box is laid out for the transform's
+// frequencies of the halo box: record (hz, f, hy, pair) at ((hz * 4 + f) * 10 + hy) * 4 + pair, slots XOR-swizzled by ((hy * NP + pair) >> 2) & 3
+// (= hy & 3 for the main shape: 16 lanes of an A-fragment read = 4 y x 4 pairs hit 16 different 16-byte bank groups).  The raw box is laid out for the transform's
 // reads, not as records: piece L = (hz * 10 + hy) * 41 + (term * 10 + hx) * 2 + half (one pad piece per row: 16 lanes = 4 y x 4 pairs
 // read 16 different bank groups); global_load_lds writes lane-linearly, so the permutation is applied to the SOURCE address.
 //
 // Epilogue: the four frequencies of an output sit in four waves.  Per cout half the waves of a group exchange accumulators through
 // LDS (wave w keeps z slice w: it sends three slices and receives three frequencies, 48 KB per group), apply the output transform,
-// scale / shift / ReLU / split as conv3_igemm_sres does, build the block's image in LDS and copy it out 16 B per lane.
+// scale / shift / ReLU / split as conv3_igemm_sres does, build the block's image in LDS and copy it out 16 B per lane; ec3 / ec5:
+// MaxPool3d(2) from that image (main shape, whole-tile boxes).  A transformed input beyond fp16's range turns its outputs NaN: the
+// outputs inside the box are tested for finiteness before the ReLU and raise the overflow bit of the range flag.
+//
+// Measured (profiles/r03_winograd.md): 0.76-0.82 of the direct kernel's time per layer at 128 couts per workgroup, nothing at 64; what
+// is left is the weight-fragment stream (36 / 27 of the direct form's bytes for 2 / 3 of its MFMAs) at the power wall.
 //
 // Every value of an output depends only on the parity of its x (pairs start at even tile coordinates: the host aligns the launch box)
 // -- not on the block grid, the batch or the launch box: results do not depend on how tiles are batched.
