@@ -612,7 +612,7 @@ template <int TY, int NP>
 static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
     for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
     if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
-    const int ng = a.Cout % 128 == 0 ? 2 : 1;
+    const int ng = (a.Cout % 128 == 0 && !((h->opt_wino & 8) && TY != 4)) ? 2 : 1;      // (bit 3, A/B: the specialised 64-cout form for every layer)
     a.wpanel = L.panel_wino;
     a.ncb = a.Cout / (64 * ng);
     a.nbz = cdiv(box.hi[0] - box.lo[0], 4); a.nby = cdiv(box.hi[1] - box.lo[1], TY); a.nbx = cdiv(box.hi[2] - box.lo[2], 2 * NP);
@@ -634,7 +634,10 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
     if (ng == 2) conv3_wino_sres<2, TY, NP><<<grid, 512, 0, st>>>(a, h->zero_rec);
-    else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);       // one block of 64 couts: the eight waves split the z slices
+    else if constexpr (TY != 4) {
+        if (h->opt_wino & 4) conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);        // (A/B: the eight waves split the z slices)
+        else conv3_wino_sres<1, TY, NP, 1, true><<<grid, 512, 0, st>>>(a, h->zero_rec);                  // one block of 64 couts: four waves multiply, four stage
+    } else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);       // (the y strip's two T buffers would not fit: the eight waves split the z slices)
     OAI_CHECK_LAUNCH();
     if (h->profile) {
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
@@ -686,7 +689,7 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
     if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.sc_boxes &&
-        (!a.pool_out || (a.Cout % 128 == 0 && wino_pool_box(box, dims))) && a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
+        (!a.pool_out || (a.Cout % 128 == 0 && wino_pool_box(box, dims))) && a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && (a.Cout % 128 == 0 || (a.C0 + 15) / 16 + (a.C1 + 15) / 16 >= 8) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
         return launch_conv3_wino(h, L, a, box, ntiles, st);
     int ny, nx, hr, wr;
     strip_plan(h, box, ny, nx, hr, wr);
@@ -1111,8 +1114,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "wide")) {
         OAI_CHECK_ARG(value >= 0 && value <= 2, "oai_unet_set_option: wide must be 0, 1 or 2 (2 = also for launches of fewer than 1024 workgroups)");
         h->opt_wide = value;
-    } else if (!strcmp(name, "winograd")) {            // bit 0: layers with Cout % 128 == 0 (two cout groups per workgroup), bit 1: Cout % 128 == 64
-        OAI_CHECK_ARG(value >= 0 && value <= 3, "oai_unet_set_option: winograd must be in [0, 3]");
+    } else if (!strcmp(name, "winograd")) {            // bit 0: layers with Cout % 128 == 0 (two cout groups per workgroup), bit 1: one block of 64 couts and >= 8 chunks
+                                                       // (specialised waves); A/B only: bit 2 = the slice-split form instead, bit 3 = the specialised form for every layer
+        OAI_CHECK_ARG(value >= 0 && value <= 15, "oai_unet_set_option: winograd must be in [0, 15]");
         if (value && !h->opt_wino && h->L[EC0].scale_f16) {
             OAI_CHECK_HIP(hipDeviceSynchronize());
             for (int k = 1; k < 17; ++k)

@@ -45,27 +45,38 @@ namespace oai {
 // MS = 2 (NG = 1, layers with ONE block of 64 couts): eight waves all the same, wave (zp, f) owns frequency f of the z slices 2 zp, 2 zp + 1
 // -- two accumulator tiles x 64 couts; the two waves of a frequency fetch the same weight fragments (the second from L1).  Four waves with
 // four tiles each (NG = 1, MS = 1) leave every SIMD with one wave: measured no faster than the direct kernel.
-template <int NG, int TY, int NP, int MS = 1>
-__global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+// WS (NG = 1, MS = 1; one block of 64 couts): the eight waves are SPECIALISED.  Waves 0-3 only multiply -- wave = frequency, four tiles x 64
+// couts per weight fragment set, the register shape of the two-group form -- and waves 4-7 only stage: each owns a quarter of the halo rows,
+// requests their pieces, transforms them into the OTHER of two T buffers while the multipliers work on the current one, and requests the next
+// chunk's pieces into the same places (no wave ever reads what another wave's DMA writes: no barrier inside the staging).  One barrier per
+// chunk; no transform phase and no halo piece in front of a weight fragment on the multipliers' path.  2 x 60 KB of T + 40 KB of raw rows =
+// the CU's 160 KB exactly.  (MS = 2 measured 0.43 MFMA-busy on dc2: its vector-memory path carries every weight fragment twice.)
+template <int NG, int TY, int NP, int MS = 1, bool WS = false>
+__global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
+    static_assert(!WS || (NG == 1 && MS == 1), "specialised waves: four multiply, four stage");
     constexpr int TZ = 4, TX = 2 * NP, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int RS = 4 * HX + 1;                                // 16-byte pieces per raw row (hz, hy): [term][hx][half] + 1 pad
     constexpr int PIECES = HZ * HY * RS;                          // 2460 for 8 x 4
     constexpr int NIT = (PIECES + NT - 1) / NT;                   // LDS-DMA instructions per thread per chunk: 5 (NG 2) / 10 (NG 1) for 8 x 4
     constexpr int TB = HZ * 4 * HY * NP * 64;                     // 61 440 bytes of T for 8 x 4
-    constexpr int RAWB = NIT * NT * 16;                           // 40 960 bytes of raw box (whole 1-KiB wave writes)
+    constexpr int RPW = HZ * HY / 4, WNIT = (RPW * RS + 63) / 64;    // WS: halo rows and LDS-DMA instructions per staging wave and chunk (15, 10)
+    constexpr int RAWB = WS ? 4 * WNIT * 1024 : NIT * NT * 16;    // 40 960 bytes of raw box (whole 1-KiB wave writes)
     constexpr int UNITS = HZ * 2 * HY * NP;                       // 480 transform units (hz, half, hy, pair)
     constexpr int XB = 3 * 4 * 4 * 1024;                          // exchange buffer of one cout group: [f][3 slices][4 row groups][lane] x 16 B
     static_assert(NG == 1 || NG == 2, "one or two cout groups");
     static_assert(TY * NP == 32 && (NP == 2 || NP == 4 || NP == 8), "32 rows per accumulator tile");
-    static_assert(TB + RAWB <= 160 * 1024 && NG * MS * XB <= TB + RAWB && TZ * TY * TX * 128 <= XB && TZ * TY * TX * 256 <= TB + RAWB, "epilogue buffers live in the idle T / raw space");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TB + RAWB];
+    constexpr int NTB = WS ? 2 : 1;                               // T buffers
+    static_assert(!WS || (HZ * HY) % 4 == 0, "whole halo rows per staging wave");
+    static_assert(NTB * TB + RAWB <= 160 * 1024 && NG * MS * XB <= TB + RAWB && TZ * TY * TX * 128 <= XB && TZ * TY * TX * 256 <= TB + RAWB, "epilogue buffers live in the idle T / raw space");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NTB * TB + RAWB];
     unsigned char* const Tl = lds;
-    unsigned char* const raw = lds + TB;
+    unsigned char* const raw = lds + NTB * TB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = MS == 2 ? 0 : wave >> 2, zp = MS == 2 ? wave >> 2 : 0, f = wave & 3, gtid = tid & 255;
+    const int grp = (MS == 2 || WS) ? 0 : wave >> 2, zp = MS == 2 ? wave >> 2 : 0, f = wave & 3, gtid = tid & 255;
+    const bool stager = WS && __builtin_amdgcn_readfirstlane(wave) >= 4;      // WS: waves 4-7 stage, waves 0-3 multiply (a scalar condition: the branches on it are uniform)
     int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
     if (id < 0) return;
     const int cbg = id % a.ncb; id /= a.ncb;                      // a.ncb = Cout / (64 NG) for this kernel
@@ -101,7 +112,7 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
     constexpr unsigned kNoPiece = 0xFFFFFFFFu;
     unsigned poff[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < (WS ? 0 : NIT); ++it) {
         const int L = it * NT + tid;
         const int rw = L / RS, c = L - rw * RS;
         const int hz = rw / HY, hy = rw - hz * HY;
@@ -121,13 +132,46 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
         lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16));
     };
     // pieces requested in tap t (for the NEXT chunk): spread over the nine taps, the early taps take the remainder
-    auto pieces_in_tap = [](int t) constexpr { return NIT / 9 + (t < NIT % 9 ? 1 : 0); };
+    auto pieces_in_tap = [](int t) constexpr { return WS ? 0 : NIT / 9 + (t < NIT % 9 ? 1 : 0); };
     auto first_piece = [](int t) constexpr { return t * (NIT / 9) + (t < NIT % 9 ? t : NIT % 9); };
     static_assert(NIT <= 18, "at most two pieces per tap (vm_wait<0..2>)");
 
     // ---- input transform of the staged chunk: raw -> T
     // (a t beyond fp16's range -- inputs <= 65504, |t| <= 131008 -- becomes the pair (inf, -inf): every output that depends on it turns NaN and
     // is reported by the epilogue's finiteness test.  Not tested here: halo voxels that no output inside the box reads may be uninitialised memory.)
+    // one unit: the four frequencies of (hz, hy, pair p, channel half hf) from the raw pieces at rb into the T buffer at Tdst
+    auto transform_unit = [&](const unsigned char* rb, int hz, int hy, int p, int hf, unsigned char* Tdst) __attribute__((always_inline)) {
+        float x[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u16x8 h0 = *reinterpret_cast<const u16x8*>(rb + (2 * i) * 16);
+            const u16x8 h1 = *reinterpret_cast<const u16x8*>(rb + (2 * HX + 2 * i) * 16);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[i][c] = join2_f16(h0[c], h1[c]);
+        }
+        unsigned char* tw = Tdst + (((hz * 4) * HY + hy) * NP + p) * 64;
+        const int key = ((hy * NP + p) >> 2) & 3;
+        const int sl0 = ((hf) ^ key) * 16, sl1 = ((2 + hf) ^ key) * 16;
+#pragma unroll
+        for (int fq = 0; fq < 4; ++fq) {
+            u16x8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                f32x2 v;
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    v[e] = fq == 0 ? x[0][c + e] - x[2][c + e] : fq == 1 ? x[1][c + e] + x[2][c + e] : fq == 2 ? x[2][c + e] - x[1][c + e] : x[1][c + e] - x[3][c + e];
+                const f16x2 h = __builtin_convertvector(v, f16x2);
+                const f32x2 res = v - __builtin_convertvector(h, f32x2);
+                const f16x2 l = __builtin_convertvector(res, f16x2);
+                const unsigned H = __builtin_bit_cast(unsigned, h), Lw = __builtin_bit_cast(unsigned, l);
+                hi[c] = (unsigned short)H; hi[c + 1] = (unsigned short)(H >> 16);
+                lo[c] = (unsigned short)Lw; lo[c + 1] = (unsigned short)(Lw >> 16);
+            }
+            *reinterpret_cast<u16x8*>(tw + fq * (HY * NP * 64) + sl0) = hi;
+            *reinterpret_cast<u16x8*>(tw + fq * (HY * NP * 64) + sl1) = lo;
+        }
+    };
     auto transform = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ui = 0; ui < (UNITS + NT - 1) / NT; ++ui) {
@@ -137,37 +181,46 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
                 int t = u / NP;
                 const int hy = t % HY; t /= HY;
                 const int hf = t & 1, hz = t >> 1;
-                const unsigned char* rb = raw + (((hz * HY + hy) * RS) + 4 * p + hf) * 16;
-                float x[4][8];
+                transform_unit(raw + (((hz * HY + hy) * RS) + 4 * p + hf) * 16, hz, hy, p, hf, Tl);
+            }
+        }
+    };
+    // ---- WS, staging waves: wave sw = wave - 4 owns the halo rows r = sw + 4 j, j < RPW, stored as [j][RS pieces] in its own 1-KiB-aligned part
+    // of the raw box.  stage_request(ch): its WNIT LDS-DMA instructions for chunk ch; stage_transform(ch): its rows -> T[ch & 1]
+    const int sw = wave & 3;
+    unsigned char* const raw_w = raw + sw * (WNIT * 1024);
+    unsigned woff[WS ? WNIT : 1];
+    if constexpr (WS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u16x8 h0 = *reinterpret_cast<const u16x8*>(rb + (2 * i) * 16);
-                    const u16x8 h1 = *reinterpret_cast<const u16x8*>(rb + (2 * HX + 2 * i) * 16);
+        for (int it = 0; it < WNIT; ++it) {
+            const int q = it * 64 + lane;
+            const int rj = q / RS, c = q - rj * RS;
+            const int r = sw + 4 * rj, hz = r / HY, hy = r - hz * HY;
+            const int term = c / (2 * HX), hx = (c - term * 2 * HX) >> 1, hf = c & 1;
+            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            const bool ok = rj < RPW && c < 4 * HX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            woff[it] = ok ? ((unsigned)((gz * a.H + gy) * a.W + gx) << 6) | (unsigned)(term * 32 + hf * 16) : kNoPiece;
+        }
+    }
+    auto stage_request = [&](int ch) __attribute__((always_inline)) {
+        const bool first = ch < nch0;
+        const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
+        const unsigned dst = lds_addr_of(raw_w);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) x[i][c] = join2_f16(h0[c], h1[c]);
-                }
-                unsigned char* tw = Tl + (((hz * 4) * HY + hy) * NP + p) * 64;
-                const int key = ((hy * NP + p) >> 2) & 3;
-                const int sl0 = ((hf) ^ key) * 16, sl1 = ((2 + hf) ^ key) * 16;
+        for (int it = 0; it < (WS ? WNIT : 0); ++it) {
+            const unsigned char* g = woff[WS ? it : 0] != kNoPiece ? cbase + woff[WS ? it : 0] : zero_rec;
+            lds_dma16(g, __builtin_amdgcn_readfirstlane(dst + it * 1024));
+        }
+    };
+    auto stage_transform = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
-                for (int fq = 0; fq < 4; ++fq) {
-                    u16x8 hi, lo;
-#pragma unroll
-                    for (int c = 0; c < 8; c += 2) {
-                        f32x2 v;
-#pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            v[e] = fq == 0 ? x[0][c + e] - x[2][c + e] : fq == 1 ? x[1][c + e] + x[2][c + e] : fq == 2 ? x[2][c + e] - x[1][c + e] : x[1][c + e] - x[3][c + e];
-                        const f16x2 h = __builtin_convertvector(v, f16x2);
-                        const f32x2 res = v - __builtin_convertvector(h, f32x2);
-                        const f16x2 l = __builtin_convertvector(res, f16x2);
-                        const unsigned H = __builtin_bit_cast(unsigned, h), Lw = __builtin_bit_cast(unsigned, l);
-                        hi[c] = (unsigned short)H; hi[c + 1] = (unsigned short)(H >> 16);
-                        lo[c] = (unsigned short)Lw; lo[c + 1] = (unsigned short)(Lw >> 16);
-                    }
-                    *reinterpret_cast<u16x8*>(tw + fq * (HY * NP * 64) + sl0) = hi;
-                    *reinterpret_cast<u16x8*>(tw + fq * (HY * NP * 64) + sl1) = lo;
-                }
+        for (int ui = 0; ui < (RPW * 2 * NP + 63) / 64; ++ui) {
+            const int idx = ui * 64 + lane;
+            if (idx < RPW * 2 * NP) {
+                const int rj = idx / (2 * NP), rem = idx - rj * 2 * NP;
+                const int p = rem % NP, hf = rem / NP;
+                const int r = sw + 4 * rj, hz = r / HY, hy = r - hz * HY;
+                transform_unit(raw_w + (rj * RS + 4 * p + hf) * 16, hz, hy, p, hf, Tl + (ch & 1) * TB);
             }
         }
     };
@@ -187,19 +240,36 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
         ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wp_v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp_v));
     const unsigned wlane = lane * 16;
 
-    // ---- prologue: the first raw box and the weight fragments of tap 0
+    // ---- prologue: the first raw box and the weight fragments of tap 0 (WS: the stagers also transform chunk 0 and request chunk 1)
+    if constexpr (!WS) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) issue_piece(it, 0);
-    f32x4 bq[2][2][NREP];                                           // [tap parity][term][n]
-    sgpr_settle(wp);                                                // wp has just been made uniform by v_readfirstlane
+        for (int it = 0; it < NIT; ++it) issue_piece(it, 0);
+    }
+    // D = taps between the request of a fragment set and its use.  WS: a multiplier has its SIMD to itself -- nobody covers a wait -- and a tap
+    // is 24 MFMAs = 0.37 us, less than an L2 round trip: D = 2, three register sets (9 % 3 == 0: the set of a tap does not depend on the chunk);
+    // the registers come from the A fragments, see the slice-major tap below
+    constexpr int D = WS ? 2 : 1, NB = D + 1;
+    f32x4 bq[NB][2][NREP];                                          // [tap % NB][term][n]
+    if (!stager) {
+        sgpr_settle(wp);                                            // wp has just been made uniform by v_readfirstlane
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+        for (int d = 0; d < D; ++d) {
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) bq[0][k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
-                                                            : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
-    wp += STEP * 16;
-    static_assert(NREP == 2, "vm_wait names four fragments");
-    vm_wait<0>(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) bq[d][k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
+                                                                    : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+            wp += STEP * 16;
+        }
+        static_assert(NREP == 2, "vm_wait names four fragments");
+        vm_wait<0>(bq[D - 1][0][0], bq[D - 1][0][1], bq[D - 1][1][0], bq[D - 1][1][1]);
+    } else {
+        stage_request(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_transform(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // its reads of the raw rows are done: they may be overwritten
+        if (nchunks > 1) stage_request(1);
+    }
     __syncthreads();
 
     auto run_chunks = [&](auto ml_tag) __attribute__((always_inline)) {
@@ -207,11 +277,63 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
         for (int ch = 0; ch < nchunks; ++ch) {
             // (-DOAI_DIAG builds, OAI_DBG bits -- timing only, results wrong: 4096 no weight-fragment loads in the taps, 8192 A fragments of tap 0 for
             // every tap, 16384 transform of chunk 0 only, 32768 no DMA pieces in the taps; scripts/wino_var.sh, profiles/r03_winograd.md)
-            if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                            // T is complete; the raw box is free for the next chunk's pieces
-            asm volatile("" ::: "memory");
-            const unsigned char* abase = Tl + aofs;
+            if constexpr (!WS) {
+                if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                        // T is complete; the raw box is free for the next chunk's pieces
+                asm volatile("" ::: "memory");
+            }
+            const unsigned char* abase = Tl + (WS ? (ch & 1) * TB : 0) + aofs;
+            if constexpr (WS) {
+                // the multiplier's chunk: 9 taps, slice-major -- per z slice m: a0[m].b0, a0[m].b1, a1[m].b0 for both cout halves (six MFMAs; every
+                // accumulator still sees a0.b0, a0.b1, a1.b0 in this order), with the fragment pair of the NEXT slice requested in front of
+                // them: one pair live + one in flight = 16 VGPRs instead of 32, the difference pays the third weight-fragment set
+                auto load_pair = [&](float4 (&dst)[2], int t, int m) __attribute__((always_inline)) {
+                    const int dz = t / 3, dy = t % 3;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) dst[k] = *reinterpret_cast<const float4*>(abase + (((m + dz) * 4 * HY + dy) * NP) * 64 + sl[dy][k]);
+                };
+                float4 aa[2][2];                                     // [step parity][term]
+                if constexpr (ML > 0) load_pair(aa[0], 0, 0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    f32x4 (&bc)[2][NREP] = bq[t % 3];
+                    f32x4 (&bn)[2][NREP] = bq[(t + 2) % 3];
+                    vm_wait<4>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);      // in flight behind B(t): the fragments of tap t+1
+                    if (!OAI_DBG_BIT(a, 4096)) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int n = 0; n < NREP; ++n)
+                                bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
+                                                  : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+                    }
+                    wp += STEP * 16;
+#pragma unroll
+                    for (int m = 0; m < ML; ++m) {
+                        constexpr int kDummy = 0; (void)kDummy;
+                        const int step = t * ML + m;                     // aa[step & 1] holds (t, m)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (m + 1 < ML) load_pair(aa[(step + 1) & 1], t, m + 1);
+                        else if (t + 1 < 9) load_pair(aa[(step + 1) & 1], t + 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        float4 (&ac)[2] = aa[step & 1];
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(ac[0], __builtin_bit_cast(float4, bc[0][n]), acc[m][n]);      // a0.b0
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(ac[0], __builtin_bit_cast(float4, bc[1][n]), acc[m][n]);      // a0.b1
+#pragma unroll
+                        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(ac[1], __builtin_bit_cast(float4, bc[0][n]), acc[m][n]);      // a1.b0
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // chunk end: the fragments of the next chunk's taps 0 and 1 stay in flight (waited for there); the barrier: the stagers have
+                // finished the other T buffer, and everybody is done reading this one
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                continue;
+            }
             auto load_a = [&](float4 (&dst)[MREP], int t, int k) __attribute__((always_inline)) {
                 const int dz = t / 3, dy = t % 3;
 #pragma unroll
@@ -276,6 +398,23 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
     };
     const int mlb = m_lo == 0 ? m_hi : TZ;                          // live z slices of the block (workgroup-uniform) ...
     const int ml = min(MREP, max(0, mlb - zp * MREP));              // ... and of this wave (wave-uniform; MS = 2: the upper pair of a 1- or 2-slice block idles through the taps)
+    if (stager) {
+        // WS, waves 4-7: while the multipliers run the taps of chunk ch, transform the rows of chunk ch + 1 (requested a chunk ago: the wait is
+        // short) into the other T buffer, then request chunk ch + 2 into the same rows; one barrier per chunk, the multipliers' chunk-end one
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch + 1 < nchunks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                stage_transform(ch + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ch + 2 < nchunks) stage_request(ch + 2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        for (int i = 0; i < 4 * NREP; ++i) __syncthreads();          // the barriers of the multipliers' epilogue
+        return;
+    }
     if constexpr (MS == 1) {
         if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
         else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
@@ -287,6 +426,7 @@ __global__ void __launch_bounds__(256 * NG * MS, 1) conv3_wino_sres(const ConvAr
         else run_chunks(std::integral_constant<int, 0>{});
     }
 
+    if constexpr (D > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // fragments requested past the last tap: never used, drained before their registers are reused
     // ---- epilogue
     constexpr int TV = TZ * TY * TX;                                // 256 voxels
     constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
