@@ -458,7 +458,7 @@ def main():
                     "mfma_passes_per_product": PASSES[prec], "executed_frac": ach_fa * PASSES[prec] / peak,
                     "executed_frac_of_sustained_issue_rate": None if prec == "f32" else ach_fa * PASSES[prec] / SUSTAINED_16BIT_MFMA_TFLOPS,
                     "executed_note": None if prec == "f32" else
-                    "executed_frac counts 3 MFMA passes per ALGORITHMIC product; the k3 layers without a fused ec0 / head (ec2-ec7 dc8 dc7 dc5 dc4 dc2, 81 % of the "
+                    "executed_frac counts 3 MFMA passes per ALGORITHMIC product; the k3 layers without a fused ec0 / head (ec3-ec7 dc8 dc7 dc5 dc4 dc2, 78 % of the "
                     "3x3x3 algorithmic FLOP) run the x axis in Winograd F(2,3) form and execute 2/3 of that (unet_wino.h, profiles/r03_winograd.md): for them "
                     "it overstates the matrix pipe's load, `frac` (algorithmic FLOP / time / peak) is the contract figure",
                     "algorithmic_flops_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
