@@ -635,7 +635,12 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
     }
     if (ng == 2) conv3_wino_sres<2, TY, NP><<<grid, 512, 0, st>>>(a, h->zero_rec);
     else if constexpr (TY != 4) {
-        if (h->opt_wino & 4) conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);        // (A/B: the eight waves split the z slices)
+        // the specialised form takes ALL of a CU's LDS (160 KB): asked once whether a workgroup of it fits this device / driver at all
+        static const bool ws_fits = [] {
+            int n = 0;
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_wino_sres<1, TY, NP, 1, true>, 512, 0) == hipSuccess && n >= 1;
+        }();
+        if ((h->opt_wino & 4) || !ws_fits) conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);        // (A/B, or no room: the eight waves split the z slices)
         else conv3_wino_sres<1, TY, NP, 1, true><<<grid, 512, 0, st>>>(a, h->zero_rec);                  // one block of 64 couts: four waves multiply, four stage
     } else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);       // (the y strip's two T buffers would not fit: the eight waves split the z slices)
     OAI_CHECK_LAUNCH();
