@@ -71,12 +71,14 @@ int oai_phi_to_itk_displacement(const float* phi_dev, int D, int H, int W, doubl
 /* A whole compose chain of icon_registration's TwoStepRegistration / DownsampleRegistration closures per output voxel, without
  * materialising the intermediate maps (SURVEY.md K15 "fuse chains", K18):
  *     c = identity(D,H,W) [+ start_dev]        start_dev [3][D][H][W] may be NULL (the package's isIdentity shortcut when given)
- *     c = c + sample(fields[i], c)             i = 0 .. n_fields-1 (n_fields <= 2), fields[i] is [3][fd][fh][fw] with
- *                                              (fd,fh,fw) = field_dims_zyx[3i..3i+2] -- usually the half-resolution grid
+ *     c = c + sample(fields[i], c)             i = 0 .. n_fields-1 (n_fields <= OAI_WARP_CHAIN_MAX_FIELDS), fields[i] is
+ *                                              [3][fd][fh][fw] with (fd,fh,fw) = field_dims_zyx[3i..3i+2] -- any resolution; a step
+ *                                              tree of N FunctionFromVectorFields flattens to N links (oai_icon_create)
  *     out = image_dev ? sample(image_dev [id][ih][iw], c)  ->  out_dev [D][H][W]
  *                     : c                                   ->  out_dev [3][D][H][W]
  * `sample` is oai_grid_sample3d's (grid_sample bilinear / border / align_corners=True on [0,1] coordinates).  Bit-identical to
  * the sequence of oai_compose / oai_grid_sample3d calls it replaces.  `fields` and `field_dims_zyx` are HOST arrays. */
+#define OAI_WARP_CHAIN_MAX_FIELDS 8
 int oai_warp_chain(const float* start_dev, int D, int H, int W, int n_fields, const float* const* fields,
                    const int* field_dims_zyx, const float* image_dev, int id, int ih, int iw, float* out_dev, void* stream);
 
@@ -294,12 +296,32 @@ typedef struct oai_icon_unet_params {
     const float* last_w; const float* last_b;
 } oai_icon_unet_params;
 
-/* nets[0], nets[1]: the two low-resolution steps; nets[2]: the full-resolution step.
- * BatchNorm3d behind every up-conv (networks.UNet2.batchNorms of the package the reference calls at registration.py:20): pass all four
+/* The registration network is a TREE of the package's wrapper modules around n_nets tallUNet2s -- whatever the checkpoint behind
+ * OAI_knees_gradICON_model (registration.py:20) holds; the nesting of `netPhi` / `netPsi` / `net` in its state_dict keys IS this
+ * tree (oai_analysis_2_amd/registration.py:parse_icon_tree):
+ *   OAI_ICON_FFVF   network_wrappers.FunctionFromVectorField(net = tallUNet2 number a): d = net(A, B) on A's grid;
+ *                   transform(x) = x + d when x is the tagged identity map of d's own shape (the isIdentity shortcut), else
+ *                   x + sample(d, x)
+ *   OAI_ICON_DOWN   DownsampleRegistration(net = node a): the child sees avg_pool3d(A, 2, ceil_mode=True), avg_pool3d(B, ...);
+ *                   its transform works in the same [0,1] coordinates
+ *   OAI_ICON_TWO    TwoStepRegistration(netPhi = node a, netPsi = node b): phi = netPhi(A, B);
+ *                   psi = netPsi(A warped by phi(identity map of A's grid), B); transform(x) = phi(psi(x))
+ * nodes[root] is regis_net.  Every node is used exactly once; a child's index differs from its parent's.  A net index may not
+ * repeat.  Limits: n_nets, chain length <= OAI_WARP_CHAIN_MAX_FIELDS; every grid a U-Net runs on needs each axis >= 17.
+ * Examples (u_k = FFVF(net k)):  SURVEY Appendix A's three-step  TWO(DOWN(TWO(u0,u1)), u2);  "the definition of our final 4 step
+ * registration network"  TWO(TWO(DOWN(TWO(u0,u1)), u2), u3);  the gradICON multi-resolution form  TWO(DOWN(TWO(DOWN(u0), u1)), u2). */
+enum { OAI_ICON_FFVF = 0, OAI_ICON_DOWN = 1, OAI_ICON_TWO = 2 };
+typedef struct oai_icon_node { int kind; int a; int b; } oai_icon_node;
+
+/* BatchNorm3d behind every up-conv (networks.UNet2.batchNorms of the package the reference calls at registration.py:20): pass all four
  * bn_* arrays of a level, or NULL for all four = no normalisation at that level.  icon_registration 1.1.2 is not vendored in the
  * reference tree and one recollection of it has the batchNorms[depth] call commented out in UNet2.forward (the parameters are in the
  * state_dict either way): the caller decides, nothing is assumed silently. */
-int oai_icon_create(const oai_icon_unet_params nets_host[3], int D, int H, int W, oai_icon** out);
+int oai_icon_create(const oai_icon_unet_params* nets_host, int n_nets, const oai_icon_node* nodes_host, int n_nodes, int root,
+                    int D, int H, int W, oai_icon** out);
+/* What the tree flattens to: n_nets, the number of launched U-Net passes per direction at each halving level (levels_host[k] =
+ * U-Nets on the grid halved k times, k < 8), and the length of the final compose chain. */
+int oai_icon_describe(const oai_icon* h, int* n_nets, int* levels_host, int* chain_len);
 void oai_icon_destroy(oai_icon* h);
 size_t oai_icon_workspace_bytes(const oai_icon* h);
 
@@ -308,7 +330,7 @@ size_t oai_icon_workspace_bytes(const oai_icon* h);
 int oai_icon_forward(oai_icon* h, const float* A_dev, const float* B_dev, float* phi_dev,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* oai_icon_forward replays its ~70 dependent launches as ONE hipGraph (captured on the first call per workspace, on an internal
+/* oai_icon_forward replays its dependent launches (~70 for three U-Nets) as ONE hipGraph (captured on the first call per workspace, on an internal
  * stream; inputs and result have fixed homes inside the workspace, copied in / out around the replay).  oai_icon_set_graph(h, 0)
  * runs the same launches directly.  oai_icon_graph_info: *captured = 1 graph in use, 0 not captured yet, -1 capture failed on this
  * runtime (direct launches are used: same kernels, same results); counts of replays / direct runs. */
@@ -319,7 +341,7 @@ int oai_icon_set_graph(oai_icon* h, int enable);
 int oai_icon_set_option(oai_icon* h, const char* name, int value);
 int oai_icon_graph_info(const oai_icon* h, int* captured, long long* replays, long long* direct_runs);
 
-/* One tallUNet2 forward on its own (unit-test seam): out[3][D][H][W] = net(a, b). */
+/* One tallUNet2 forward on its own (unit-test seam): out[3][D][H][W] = net number `which` (a, b). */
 int oai_icon_unet_forward(oai_icon* h, int which, const float* a_dev, const float* b_dev, int D, int H, int W,
                           float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 

@@ -31,6 +31,10 @@ class IconUnetParams(C.Structure):
                 ("last_w", C.c_void_p), ("last_b", C.c_void_p)]
 
 
+class IconNode(C.Structure):              # == struct oai_icon_node
+    _fields_ = [("kind", C.c_int), ("a", C.c_int), ("b", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/oai_hip.h
 _I, _P, _F, _Z, _D = C.c_int, C.c_void_p, C.c_float, C.c_size_t, C.c_double
 _I3 = C.POINTER(C.c_int)
@@ -81,7 +85,8 @@ SIGNATURES = {
     "oai_unet_tile_flops_conv3": (_D, [_P, _I, _I, _I, _I3, _I]),
     "oai_unet_profile": (_I, [_P, _I]),
     "oai_unet_profile_read": (_I, [_P, C.POINTER(_D), C.POINTER(C.c_longlong)]),
-    "oai_icon_create": (_I, [C.POINTER(IconUnetParams), _I, _I, _I, C.POINTER(_P)]),
+    "oai_icon_create": (_I, [C.POINTER(IconUnetParams), _I, C.POINTER(IconNode), _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "oai_icon_describe": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "oai_icon_destroy": (None, [_P]),
     "oai_icon_workspace_bytes": (_Z, [_P]),
     "oai_icon_forward": (_I, [_P, _P, _P, _P, _P, _Z, _P]),

@@ -1,5 +1,7 @@
-// ICON gradICON registration network on gfx950: three tallUNet2s + the warp/compose chain of
-// TwoStep(Downsample(TwoStep(FFVF(u1),FFVF(u2))), FFVF(u3)).  Restates icon_registration 1.1.2
+// ICON gradICON registration network on gfx950: N tallUNet2s + the warp/compose chains of whatever tree of
+// TwoStepRegistration / DownsampleRegistration / FunctionFromVectorField wrappers the checkpoint holds, e.g.
+// TwoStep(Downsample(TwoStep(FFVF(u1),FFVF(u2))), FFVF(u3)) or the four-step form with one more
+// full-resolution FFVF around it; the tree is compiled into a linear plan at oai_icon_create.  Restates icon_registration 1.1.2
 // (see oracle/icon.py; reference call sites oai_analysis/registration.py:20,25).
 //
 // The nets are 0.1 TFLOP per direction against 80-156 TFLOP for the segmentation U-Net, with
@@ -406,11 +408,34 @@ struct NetWeights {
 
 }  // namespace
 
+// One launch group of a direction, compiled from the step tree (plan_tree below).  Buffers are float offsets into the workspace.
+struct IconStep {
+    enum Kind { POOL, UNET, CHAIN } kind;
+    int lvl = 0;                          // grid = the network shape halved lvl times (ceil)
+    // POOL: src (lvl) -> dst (lvl + 1).  UNET: net(a, b) -> out [3][grid].  CHAIN: out = image ? image(c) : c with
+    // c = id(lvl) [+ start]; c += sample(field_i, c)
+    int net = -1;
+    size_t src = 0, src2 = 0, dst = 0;
+    bool has_start = false, has_image = false;
+    size_t start = 0;
+    int nf = 0;
+    size_t field[OAI_WARP_CHAIN_MAX_FIELDS];
+    int field_lvl[OAI_WARP_CHAIN_MAX_FIELDS];
+};
+
 struct oai_icon {
-    NetWeights net[3];
+    std::vector<NetWeights> net;
+    std::vector<oai_icon_node> nodes;
+    int root = 0;
     int D, H, W;
     std::vector<void*> allocs;
-    // hipGraph replay of the ~70 dependent launches of one direction (oai_icon_forward): captured once per workspace on an
+    // the compiled direction: offsets of A, B, phi (fixed homes: what the captured graph reads and writes), of the U-Net scratch,
+    // and the steps in launch order
+    std::vector<IconStep> steps;
+    size_t off_A = 0, off_B = 0, off_phi = 0, off_unet = 0, ws_floats = 0;
+    int nets_at_level[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int chain_len = 0;
+    // hipGraph replay of the dependent launches of one direction (oai_icon_forward; ~70 for three U-Nets): captured once per workspace on an
     // internal stream (the caller's stream may be the legacy null stream, which cannot be captured), replayed on the caller's.
     bool use_graph = true, graph_broken = false;
     bool pad_front = true;            // pad_or_crop's zero channels in front or behind (option "pad_front")
@@ -558,40 +583,135 @@ bool dims_ok(int D, int H, int W) {
     return true;
 }
 
-struct Ws {
-    float *a, *b, *d1, *d2, *d3, *aw, *c1, *c2, *Aw, *unet;
-    float *A, *B, *phi;          // fixed homes of the inputs and of the result: what the captured graph reads and writes
-    size_t total_bytes;
+// ---- the step tree -> a linear plan ---------------------------------------------------------------------------------------
+// network_wrappers of the package, restated (oracle/icon.py:forward_tree is the same recursion on torch CPU ops):
+//   FFVF(net k).forward(A, B):       d_k = net_k(A, B) on A's grid; closure = [d_k]
+//   Downsample(n).forward(A, B):     n.forward(avg_pool(A), avg_pool(B)); the closure is the child's
+//   TwoStep(phi, psi).forward(A, B): F_phi = phi.forward(A, B); A_w = A sampled at F_phi(identity of A's grid);
+//                                    F_psi = psi.forward(A_w, B); closure x -> phi(psi(x)) = links F_psi then F_phi
+// A closure is the list of its displacement fields in APPLICATION order; applied to the tagged identity map of a grid, the first
+// link is `id + d` when d lives on that same grid (isIdentity shortcut) and `id + sample(d, id)` otherwise, every later link is
+// `c + sample(d, c)`: exactly one oai_warp_chain launch, with the warped image as its last gather when there is one.
+struct Link { size_t off; int lvl; };
+
+struct TreePlanner {
+    oai_icon* h;
+    long long vox[8];
+    int gd[8][3];
+    size_t cur = 0;               // floats
+    std::vector<std::pair<std::pair<size_t, int>, size_t>> pooled;      // (source offset, source level) -> pooled buffer
+    std::vector<char> node_used, net_used;
+    int err = OAI_OK;
+
+    size_t take(size_t floats) { size_t o = cur; cur += align256(floats * 4) / 4; return o; }
+
+    int fail(const char* msg, int v) { if (!err) err = oai::set_error(OAI_ERR_ARG, msg, v); return err; }
+
+    size_t pool(size_t src, int lvl) {
+        for (auto& e : pooled) if (e.first.first == src && e.first.second == lvl) return e.second;
+        IconStep st; st.kind = IconStep::POOL; st.lvl = lvl; st.src = src; st.dst = take(vox[lvl + 1]);
+        h->steps.push_back(st);
+        pooled.push_back({{src, lvl}, st.dst});
+        return st.dst;
+    }
+
+    void chain(const std::vector<Link>& F, int lvl, bool has_image, size_t image, size_t out) {
+        IconStep st; st.kind = IconStep::CHAIN; st.lvl = lvl; st.dst = out; st.has_image = has_image; st.src = image;
+        size_t i = 0;
+        if (!F.empty() && F[0].lvl == lvl) { st.has_start = true; st.start = F[0].off; i = 1; }
+        for (; i < F.size(); ++i) { st.field[st.nf] = F[i].off; st.field_lvl[st.nf] = F[i].lvl; ++st.nf; }
+        h->steps.push_back(st);
+    }
+
+    std::vector<Link> eval(int node, size_t A, size_t B, int lvl, int depth) {
+        std::vector<Link> none;
+        if (err) return none;
+        if (node < 0 || node >= (int)h->nodes.size()) { fail("oai_icon_create: node index %d out of range", node); return none; }
+        if (depth > 32 || node_used[node]) { fail("oai_icon_create: node %d is used twice (the step tree must be a tree)", node); return none; }
+        node_used[node] = 1;
+        const oai_icon_node nd = h->nodes[node];
+        if (nd.kind == OAI_ICON_FFVF) {
+            if (nd.a < 0 || nd.a >= (int)h->net.size()) { fail("oai_icon_create: FFVF names net %d, which does not exist", nd.a); return none; }
+            if (net_used[nd.a]) { fail("oai_icon_create: net %d is used by two FFVF nodes", nd.a); return none; }
+            net_used[nd.a] = 1;
+            if (!dims_ok(gd[lvl][0], gd[lvl][1], gd[lvl][2])) {
+                fail("oai_icon_create: the grid of net %d is too small for five 2x poolings (each axis must be >= 17)", nd.a);
+                return none;
+            }
+            IconStep st; st.kind = IconStep::UNET; st.lvl = lvl; st.net = nd.a; st.src = A; st.src2 = B; st.dst = take(3 * vox[lvl]);
+            h->steps.push_back(st);
+            ++h->nets_at_level[lvl];
+            return {Link{st.dst, lvl}};
+        }
+        if (nd.kind == OAI_ICON_DOWN) {
+            if (lvl + 1 >= 8 || gd[lvl][0] < 2 || gd[lvl][1] < 2 || gd[lvl][2] < 2) { fail("oai_icon_create: too many Downsample levels at node %d", node); return none; }
+            const size_t a = pool(A, lvl), b = pool(B, lvl);
+            return eval(nd.a, a, b, lvl + 1, depth + 1);
+        }
+        if (nd.kind == OAI_ICON_TWO) {
+            std::vector<Link> Fphi = eval(nd.a, A, B, lvl, depth + 1);
+            if (err) return none;
+            const size_t Aw = take(vox[lvl]);
+            if ((int)Fphi.size() > OAI_WARP_CHAIN_MAX_FIELDS) { fail("oai_icon_create: more than %d steps in one chain", OAI_WARP_CHAIN_MAX_FIELDS); return none; }
+            chain(Fphi, lvl, true, A, Aw);
+            std::vector<Link> F = eval(nd.b, Aw, B, lvl, depth + 1);
+            if (err) return none;
+            F.insert(F.end(), Fphi.begin(), Fphi.end());
+            return F;
+        }
+        fail("oai_icon_create: node %d has an unknown kind", node);
+        return none;
+    }
 };
 
-Ws plan_ws(int D, int H, int W, char* base) {
-    const long long vh = (long long)D * H * W;
-    const int d = (D + 1) / 2, h = (H + 1) / 2, w = (W + 1) / 2;
-    const long long vl = (long long)d * h * w;
-    size_t o = 0;
-    auto take = [&](size_t floats) { float* p = (float*)(base + o); o += align256(floats * 4); return p; };
-    Ws s;
-    s.a = take(vl); s.b = take(vl); s.d1 = take(3 * vl); s.d2 = take(3 * vl); s.aw = take(vl);
-    s.d3 = take(3 * vh); s.c1 = nullptr; s.c2 = nullptr; s.Aw = take(vh);     // (c1, c2: never materialised since the chains are fused)
-
-    s.unet = take(unet_ws_floats(D, H, W));
-    s.A = take(vh); s.B = take(vh); s.phi = take(3 * vh);
-    s.total_bytes = o;
-    return s;
+int plan_tree(oai_icon* h) {
+    TreePlanner P;
+    P.h = h;
+    int d = h->D, hh = h->H, w = h->W;
+    for (int l = 0; l < 8; ++l) {
+        P.gd[l][0] = d; P.gd[l][1] = hh; P.gd[l][2] = w;
+        P.vox[l] = (long long)d * hh * w;
+        d = (d + 1) / 2; hh = (hh + 1) / 2; w = (w + 1) / 2;
+    }
+    P.node_used.assign(h->nodes.size(), 0);
+    P.net_used.assign(h->net.size(), 0);
+    h->steps.clear();
+    h->off_A = P.take(P.vox[0]); h->off_B = P.take(P.vox[0]);
+    std::vector<Link> F = P.eval(h->root, h->off_A, h->off_B, 0, 0);
+    if (P.err) return P.err;
+    if ((int)F.size() > OAI_WARP_CHAIN_MAX_FIELDS)
+        return oai::set_error(OAI_ERR_ARG, "oai_icon_create: %d steps in the final chain (limit %d)", (int)F.size(), OAI_WARP_CHAIN_MAX_FIELDS);
+    for (size_t n = 0; n < P.net_used.size(); ++n)
+        if (!P.net_used[n]) return oai::set_error(OAI_ERR_ARG, "oai_icon_create: net %d is not used by the step tree", (int)n);
+    for (size_t n = 0; n < P.node_used.size(); ++n)
+        if (!P.node_used[n]) return oai::set_error(OAI_ERR_ARG, "oai_icon_create: node %d is not reachable from the root", (int)n);
+    h->off_phi = P.take(3 * P.vox[0]);
+    P.chain(F, 0, false, 0, h->off_phi);
+    h->chain_len = (int)F.size();
+    int top = 0;
+    while (top < 8 && !h->nets_at_level[top]) ++top;          // the largest grid a U-Net runs on sizes the shared U-Net scratch
+    h->off_unet = P.take(unet_ws_floats(P.gd[top][0], P.gd[top][1], P.gd[top][2]));
+    h->ws_floats = P.cur;
+    return OAI_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-int oai_icon_create(const oai_icon_unet_params nets[3], int D, int H, int W, oai_icon** out) {
-    OAI_CHECK_ARG(nets && out, "oai_icon_create: null pointer");
-    OAI_CHECK_ARG(dims_ok((D + 1) / 2, (H + 1) / 2, (W + 1) / 2),
-                  "oai_icon_create: network shape %dx%dx%d too small (each low-resolution axis must be >= 17)", D, H, W);
+int oai_icon_create(const oai_icon_unet_params* nets, int n_nets, const oai_icon_node* nodes, int n_nodes, int root,
+                    int D, int H, int W, oai_icon** out) {
+    OAI_CHECK_ARG(nets && nodes && out, "oai_icon_create: null pointer");
+    OAI_CHECK_ARG(n_nets >= 1 && n_nets <= OAI_WARP_CHAIN_MAX_FIELDS, "oai_icon_create: 1..%d U-Nets", OAI_WARP_CHAIN_MAX_FIELDS);
+    OAI_CHECK_ARG(n_nodes >= 1 && n_nodes <= 64 && root >= 0 && root < n_nodes, "oai_icon_create: bad node list");
+    OAI_CHECK_ARG(D > 1 && H > 1 && W > 1, "oai_icon_create: bad network shape");
     oai_icon* h = new oai_icon();
     h->D = D; h->H = H; h->W = W;
-    int rc = OAI_OK;
-    for (int n = 0; n < 3 && rc == OAI_OK; ++n) {
+    h->net.resize(n_nets);
+    h->nodes.assign(nodes, nodes + n_nodes);
+    h->root = root;
+    int rc = plan_tree(h);
+    for (int n = 0; n < n_nets && rc == OAI_OK; ++n) {
         const oai_icon_unet_params& p = nets[n];
         NetWeights& nw = h->net[n];
         for (int l = 0; l < 5 && rc == OAI_OK; ++l) {
@@ -638,53 +758,65 @@ void oai_icon_destroy(oai_icon* h) {
 
 size_t oai_icon_workspace_bytes(const oai_icon* h) {
     if (!h) return 0;
-    return plan_ws(h->D, h->H, h->W, nullptr).total_bytes;
+    return h->ws_floats * sizeof(float);
+}
+
+int oai_icon_describe(const oai_icon* h, int* n_nets, int* levels, int* chain_len) {
+    OAI_CHECK_ARG(h, "oai_icon_describe: null handle");
+    if (n_nets) *n_nets = (int)h->net.size();
+    if (levels) for (int l = 0; l < 8; ++l) levels[l] = h->nets_at_level[l];
+    if (chain_len) *chain_len = h->chain_len;
+    return OAI_OK;
 }
 
 int oai_icon_unet_forward(oai_icon* h, int which, const float* a, const float* b, int D, int H, int W, float* out,
                           void* ws, size_t ws_bytes, void* stream) {
     OAI_CHECK_ARG(h && a && b && out && ws, "oai_icon_unet_forward: null pointer");
-    OAI_CHECK_ARG(which >= 0 && which < 3, "oai_icon_unet_forward: net index must be 0..2");
+    OAI_CHECK_ARG(which >= 0 && which < (int)h->net.size(), "oai_icon_unet_forward: net index must be 0..%d", (int)h->net.size() - 1);
     OAI_CHECK_ARG(dims_ok(D, H, W), "oai_icon_unet_forward: %dx%dx%d too small for five 2x poolings (each axis >= 17)", D, H, W);
     if (unet_ws_floats(D, H, W) * 4 > ws_bytes)
         return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_unet_forward: workspace %zu B < %zu B", ws_bytes, unet_ws_floats(D, H, W) * 4);
     return unet_forward(h->net[which], h->pad_front, a, b, D, H, W, out, (float*)ws, (hipStream_t)stream);
 }
 
-// the launches of one direction, on `st`, reading s.A / s.B and writing s.phi (all inside the workspace)
-static int icon_forward_body(oai_icon* h, const Ws& s, hipStream_t st) {
-    const int D = h->D, H = h->H, W = h->W;
-    const int d = (D + 1) / 2, hh = (H + 1) / 2, w = (W + 1) / 2;
-    const float *A = s.A, *B = s.B;
-    int rc;
-#define RUN(x) do { rc = (x); if (rc) return rc; } while (0)
-    RUN(oai_avgpool2_3d(A, 1, D, H, W, s.a, st));                                  // DownsampleRegistration.forward
-    RUN(oai_avgpool2_3d(B, 1, D, H, W, s.b, st));
-    RUN(unet_forward(h->net[0], h->pad_front, s.a, s.b, d, hh, w, s.d1, s.unet, st));            // FFVF(u1)
-    // the warp / compose closures run as fused chains (oai_warp_chain, warp.hip): bit-identical to the op-by-op sequence of
-    // oai_compose / oai_grid_sample3d calls (tests/test_warp_gpu.py), none of c1..c4 is materialised
-    const float* f21[2] = {s.d2, s.d1};
-    const int low[6] = {d, hh, w, d, hh, w};
-    RUN(oai_warp_chain(s.d1, d, hh, w, 0, nullptr, nullptr, s.a, d, hh, w, s.aw, st));        // a warped by id_l + d1 (isIdentity shortcut)
-    RUN(unet_forward(h->net[1], h->pad_front, s.aw, s.b, d, hh, w, s.d2, s.unet, st));           // FFVF(u2)
-    // c1 = id_h + sample(d2, id_h); c2 = c1 + sample(d1, c1); A warped by c2
-    RUN(oai_warp_chain(nullptr, D, H, W, 2, f21, low, A, D, H, W, s.Aw, st));
-    RUN(unet_forward(h->net[2], h->pad_front, s.Aw, B, D, H, W, s.d3, s.unet, st));              // FFVF(u3)
-    // c3 = id_h + d3 (shortcut); c4 = c3 + sample(d2, c3); phi = c4 + sample(d1, c4)
-    RUN(oai_warp_chain(s.d3, D, H, W, 2, f21, low, nullptr, 0, 0, 0, s.phi, st));
-#undef RUN
+// the launches of one direction, on `st`, reading A / B and writing phi at their fixed homes inside the workspace
+static int icon_forward_body(oai_icon* h, float* ws, hipStream_t st) {
+    int gd[8][3];
+    int d = h->D, hh = h->H, w = h->W;
+    for (int l = 0; l < 8; ++l) { gd[l][0] = d; gd[l][1] = hh; gd[l][2] = w; d = (d + 1) / 2; hh = (hh + 1) / 2; w = (w + 1) / 2; }
+    for (const IconStep& s : h->steps) {
+        const int* g = gd[s.lvl];
+        int rc = OAI_OK;
+        if (s.kind == IconStep::POOL) {                                                   // DownsampleRegistration.forward
+            rc = oai_avgpool2_3d(ws + s.src, 1, g[0], g[1], g[2], ws + s.dst, st);
+        } else if (s.kind == IconStep::UNET) {                                            // FunctionFromVectorField: d = net(A, B)
+            rc = unet_forward(h->net[s.net], h->pad_front, ws + s.src, ws + s.src2, g[0], g[1], g[2], ws + s.dst, ws + h->off_unet, st);
+        } else {
+            // the warp / compose closures run as fused chains (oai_warp_chain, warp.hip): bit-identical to the op-by-op sequence of
+            // oai_compose / oai_grid_sample3d calls (tests/test_warp_gpu.py), no intermediate map is materialised
+            const float* f[OAI_WARP_CHAIN_MAX_FIELDS];
+            int fdims[3 * OAI_WARP_CHAIN_MAX_FIELDS];
+            for (int i = 0; i < s.nf; ++i) {
+                f[i] = ws + s.field[i];
+                for (int k = 0; k < 3; ++k) fdims[3 * i + k] = gd[s.field_lvl[i]][k];
+            }
+            rc = oai_warp_chain(s.has_start ? ws + s.start : nullptr, g[0], g[1], g[2], s.nf, f, fdims,
+                                s.has_image ? ws + s.src : nullptr, g[0], g[1], g[2], ws + s.dst, st);
+        }
+        if (rc) return rc;
+    }
     return OAI_OK;
 }
 
 int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, void* ws, size_t ws_bytes, void* stream) {
     OAI_CHECK_ARG(h && A && B && phi && ws, "oai_icon_forward: null pointer");
     const long long vh = (long long)h->D * h->H * h->W;
-    Ws s = plan_ws(h->D, h->H, h->W, (char*)ws);
-    if (s.total_bytes > ws_bytes)
-        return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_forward: workspace %zu B < %zu B", ws_bytes, s.total_bytes);
+    if (h->ws_floats * sizeof(float) > ws_bytes)
+        return oai::set_error(OAI_ERR_WORKSPACE, "oai_icon_forward: workspace %zu B < %zu B", ws_bytes, h->ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = copy_f32(A, s.A, vh, st)) return rc;
-    if (int rc = copy_f32(B, s.B, vh, st)) return rc;
+    float* wsf = (float*)ws;
+    if (int rc = copy_f32(A, wsf + h->off_A, vh, st)) return rc;
+    if (int rc = copy_f32(B, wsf + h->off_B, vh, st)) return rc;
     bool replayed = false;
     if (h->use_graph && !h->graph_broken) {
         if (!h->gexec || h->g_ws != ws) {                       // first call (or another workspace): capture, do not execute
@@ -692,7 +824,7 @@ int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, vo
             if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->graph_broken = true;
             hipGraph_t g = nullptr;
             if (!h->graph_broken && hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int rc = icon_forward_body(h, s, h->cap_stream);
+                const int rc = icon_forward_body(h, wsf, h->cap_stream);
                 const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
                 if (rc != OAI_OK || e != hipSuccess || !g || hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0) != hipSuccess) {
                     h->gexec = nullptr;
@@ -710,10 +842,10 @@ int oai_icon_forward(oai_icon* h, const float* A, const float* B, float* phi, vo
         }
     }
     if (!replayed) {
-        if (int rc = icon_forward_body(h, s, st)) return rc;
+        if (int rc = icon_forward_body(h, wsf, st)) return rc;
         ++h->direct_runs;
     }
-    return copy_f32(s.phi, phi, 3 * vh, st);
+    return copy_f32(wsf + h->off_phi, phi, 3 * vh, st);
 }
 
 int oai_icon_set_graph(oai_icon* h, int enable) {

@@ -141,10 +141,11 @@ sample_kernel(const float* __restrict__ src, int C_rt, int d, int h, int w,
 // round to fp32 in memory is the same fp32 value in a register, so the result is bit-identical to the chain of
 // oai_compose / oai_grid_sample3d calls it replaces (tests/test_warp_gpu.py), while the traffic drops from ~25 B per voxel and
 // link to the compulsory 12 B (start) + 12 x (field voxels / output voxels) per field + 12 (or 4 + 4 for WARP) B written.
+constexpr int kMaxChainFields = OAI_WARP_CHAIN_MAX_FIELDS;     // include/oai_hip.h
 struct ChainArgs {
     const float* start;                  // [3][D][H][W] or nullptr
-    const float* field[2];               // [3][fd][fh][fw]
-    int fd[2], fh[2], fw[2];
+    const float* field[kMaxChainFields]; // [3][fd][fh][fw]
+    int fd[kMaxChainFields], fh[kMaxChainFields], fw[kMaxChainFields];
     int nf;
     const float* image;                  // WARP: [id][ih][iw]
     int id, ih, iw;
@@ -180,9 +181,11 @@ chain_kernel(const ChainArgs a) {
             for (int k = 0; k < 3; ++k) c[k][u] = c[k][u] + a.start[k * plane_out + lin[u]];      // add_identity_kernel: id + disp
         }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i < a.nf) {
+    // one link per field, in application order (a step tree of N FunctionFromVectorFields flattens to N links, icon.hip); the loop
+    // is not unrolled: the index into the kernel arguments is wave-uniform (scalar loads)
+#pragma unroll 1
+    for (int i = 0; i < a.nf; ++i) {
+        {
             const int plane = a.fd[i] * a.fh[i] * a.fw[i];
             Taps t[U];
 #pragma unroll
@@ -505,7 +508,7 @@ int oai_warp_chain(const float* start, int D, int H, int W, int n_fields, const 
                    const float* image, int id, int ih, int iw, float* out, void* stream) {
     OAI_CHECK_ARG(out, "oai_warp_chain: null output");
     OAI_CHECK_ARG(D > 1 && H > 1 && W > 1, "oai_warp_chain: output axes must be > 1");
-    OAI_CHECK_ARG(n_fields >= 0 && n_fields <= 2, "oai_warp_chain: 0..2 fields per call");
+    OAI_CHECK_ARG(n_fields >= 0 && n_fields <= kMaxChainFields, "oai_warp_chain: 0..%d fields per call", kMaxChainFields);
     OAI_CHECK_ARG(n_fields == 0 || (fields && field_dims), "oai_warp_chain: null field list");
     OAI_CHECK_ARG((long long)3 * D * H * W < (1LL << 31), "oai_warp_chain: output grid too large (32-bit offsets)");
     ChainArgs a{};

@@ -83,13 +83,13 @@ def compose(disp: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optio
 @_on_tensor_device
 def warp_chain(out_shape: Sequence[int], fields: Sequence[torch.Tensor] = (), start: Optional[torch.Tensor] = None,
                image: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """c = identity(out_shape) [+ start]; c = c + sample(f, c) for f in fields (<= 2); returns sample(image, c) [D,H,W] when an
+    """c = identity(out_shape) [+ start]; c = c + sample(f, c) for f in fields (<= 8 = OAI_WARP_CHAIN_MAX_FIELDS); returns sample(image, c) [D,H,W] when an
     image [d,h,w] is given, else c [3,D,H,W].  One launch, bit-identical to the compose / grid_sample3d calls it replaces."""
     lib = _lib.load()
     D, H, W = (int(v) for v in out_shape)
     fields = [_chk(f, "field") for f in fields]
-    if len(fields) > 2 or any(f.dim() != 4 or f.shape[0] != 3 for f in fields):
-        raise ValueError("at most two fields, each [3,d,h,w]")
+    if len(fields) > 8 or any(f.dim() != 4 or f.shape[0] != 3 for f in fields):
+        raise ValueError("at most eight fields, each [3,d,h,w]")
     dev = (fields[0] if fields else start if start is not None else image).device
     if start is not None:
         start = _chk(start, "start")

@@ -90,47 +90,115 @@ class DisplacementTransform:
 
 
 # --------------------------------------------------------------------------------------------------
-# engine: three tallUNet2s resident on the GPU + the warp/compose chain, all in liboai_hip.so
+# engine: N tallUNet2s resident on the GPU + the warp/compose chains of the checkpoint's step tree, all in liboai_hip.so
 
-_NET_PREFIXES = ("netPhi.net.netPhi.net.", "netPhi.net.netPsi.net.", "netPsi.net.")   # u1, u2 (low-res), u3
+FFVF, DOWN, TWO = 0, 1, 2                      # include/oai_hip.h: OAI_ICON_FFVF / _DOWN / _TWO
+_UNET_LEAVES = ("downConvs", "upConvs", "batchNorms", "lastConv", "residues")   # attribute names of networks.UNet2
+_BUFFER_LEAVES = ("identity_map", "spacing", "num_batches_tracked", "_extra_state")
 
 
-def map_icon_state_dict(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    """Keys of the three tallUNet2s out of whatever the caller holds: the ``regis_net`` state_dict itself, the whole
+@dataclass
+class IconTree:
+    """The module tree of ``regis_net`` as the library wants it (``oai_icon_create``): ``nodes[i] = (kind, a, b)`` with kind FFVF
+    (a = U-Net number), DOWN (a = child node) or TWO (a = netPhi node, b = netPsi node); ``net_prefixes[k]`` = state_dict prefix of
+    U-Net k's parameters.  U-Nets are numbered in execution order (netPhi before netPsi)."""
+    nodes: list
+    root: int
+    net_prefixes: list
+
+    def describe(self, node: Optional[int] = None) -> str:
+        kind, a, b = self.nodes[self.root if node is None else node]
+        if kind == FFVF:
+            return f"u{a}"
+        if kind == DOWN:
+            return f"Down({self.describe(a)})"
+        return f"TwoStep({self.describe(a)}, {self.describe(b)})"
+
+
+def parse_icon_tree(keys) -> IconTree:
+    """The nesting of ``netPhi`` / ``netPsi`` / ``net`` in the parameter names IS the module tree of the package's wrappers
+    (``TwoStepRegistration(netPhi, netPsi)``, ``DownsampleRegistration(net)``, ``FunctionFromVectorField(net)`` around
+    ``networks.tallUNet2``; reference call site registration.py:20): a module with children {netPhi, netPsi} is a TwoStep, one whose
+    only child ``net`` holds U-Net parameters is an FFVF, one whose ``net`` is another wrapper is a Downsample.  Anything else raises
+    ``KeyError`` -- a foreign state_dict must not load."""
+    keys = [k for k in keys if k.rsplit(".", 1)[-1] not in _BUFFER_LEAVES]
+    nodes, prefixes = [], []
+
+    def children(prefix):
+        return sorted({k[len(prefix):].split(".", 1)[0] for k in keys if k.startswith(prefix)})
+
+    def visit(prefix):
+        kids = children(prefix)
+        if kids == ["netPhi", "netPsi"]:
+            a = visit(prefix + "netPhi.")
+            b = visit(prefix + "netPsi.")
+            nodes.append((TWO, a, b))
+        elif kids == ["net"]:
+            grand = children(prefix + "net.")
+            if grand and all(g in _UNET_LEAVES for g in grand):
+                prefixes.append(prefix + "net.")
+                nodes.append((FFVF, len(prefixes) - 1, 0))
+            elif grand in (["netPhi", "netPsi"], ["net"]):
+                a = visit(prefix + "net.")
+                nodes.append((DOWN, a, 0))
+            else:
+                raise KeyError(f"unexpected keys in the ICON state_dict under '{prefix}net.': {grand[:4]}")
+        else:
+            raise KeyError(f"unexpected keys in the ICON state_dict under '{prefix}': {kids[:4]}")
+        return len(nodes) - 1
+
+    root = visit("")
+    return IconTree(nodes, root, prefixes)
+
+
+def map_icon_state_dict(state_dict: Dict[str, torch.Tensor], with_tree: bool = False):
+    """U-Net parameters (and the step tree) out of whatever the caller holds: the ``regis_net`` state_dict itself, the whole
     ``GradientICON`` module's (keys prefixed ``regis_net.``), or a checkpoint dict wrapping either.  Non-parameter entries of the
     package's modules are recognised and dropped -- the registered ``identity_map`` / ``spacing`` buffers of every wrapper level
-    and BatchNorm's ``num_batches_tracked`` -- anything else that is not a U-Net parameter raises (a wrong file should not load)."""
+    and BatchNorm's ``num_batches_tracked`` -- anything else that is not a parameter of a tallUNet2 inside the wrapper tree raises
+    (a wrong file should not load).  The tree is whatever the keys spell: SURVEY Appendix A's three steps, the four-step form with
+    a second full-resolution U-Net, a multi-resolution cascade (``parse_icon_tree``)."""
     sd = state_dict
     for wrap in ("model_state_dict", "state_dict"):
         if wrap in sd and isinstance(sd[wrap], dict):
             sd = sd[wrap]
     if any(k.startswith("regis_net.") for k in sd):
         sd = {k[len("regis_net."):]: v for k, v in sd.items() if k.startswith("regis_net.")}
-    out, unknown = {}, []
-    for k, v in sd.items():
-        leaf = k.rsplit(".", 1)[-1]
-        if leaf in ("identity_map", "spacing", "num_batches_tracked", "_extra_state"):
-            continue
-        if any(k.startswith(pre) for pre in _NET_PREFIXES):
-            out[k] = v
-        else:
-            unknown.append(k)
+    params = {k: v for k, v in sd.items() if k.rsplit(".", 1)[-1] not in _BUFFER_LEAVES}
+    tree = parse_icon_tree(params.keys())
+    expected = set()
+    for pre in tree.net_prefixes:
+        for d in range(5):
+            expected |= {f"{pre}downConvs.{d}.weight", f"{pre}downConvs.{d}.bias", f"{pre}upConvs.{d}.weight", f"{pre}upConvs.{d}.bias"}
+            expected |= {f"{pre}batchNorms.{d}.{n}" for n in ("weight", "bias", "running_mean", "running_var")}
+        expected |= {f"{pre}lastConv.weight", f"{pre}lastConv.bias"}
+    unknown = sorted(set(params) - expected)
     if unknown:
-        raise KeyError(f"unexpected keys in the ICON state_dict: {sorted(unknown)[:4]}")
-    return out
+        raise KeyError(f"unexpected keys in the ICON state_dict: {unknown[:4]}")
+    missing = sorted(k for k in expected - set(params) if ".batchNorms." not in k)
+    if missing:
+        raise KeyError(f"ICON state_dict is missing {missing[:4]}")
+    for pre in tree.net_prefixes:             # tallUNet2 = UNet2(5, [[2,16,32,64,256,512],[16,32,64,128,256]], 3): nothing else is built
+        if tuple(params[f"{pre}downConvs.0.weight"].shape) != (16, 2, 3, 3, 3) or tuple(params[f"{pre}lastConv.weight"].shape) != (3, 18, 3, 3, 3) \
+                or tuple(params[f"{pre}upConvs.4.weight"].shape) != (512, 256, 4, 4, 4):
+            raise KeyError(f"'{pre}' is not a 3-D tallUNet2 (channel widths differ)")
+    return (params, tree) if with_tree else params
 
 
 class IconEngine:
-    """``OAI_knees_gradICON_model().regis_net`` as packed weights + HIP kernels.
+    """``OAI_knees_gradICON_model().regis_net`` as packed weights + HIP kernels; the step tree is read from the state_dict's keys
+    (``self.tree``), nothing about the number of U-Nets or their resolutions is assumed.
 
     ``apply_bn`` / ``pad_front``: the two points where the restatement of the un-vendored ``icon_registration`` 1.1.2 rests on
     recollection (oracle/icon.py:OPTIONS): eval-mode BatchNorm3d behind every up-conv or none, and the side on which
-    ``pad_or_crop`` adds zero channels.  Defaults as in SURVEY Appendix A."""
+    ``pad_or_crop`` adds zero channels.  Defaults: no BatchNorm (round 4: two independent recollections of the package's
+    ``UNet2.forward`` have the ``batchNorms[depth]`` call commented out -- the ModuleList only exists in ``__init__``, which is why
+    the keys are in the state_dict), zero channels in front."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], net_shape: Sequence[int] = NET_SHAPE, device=None,
-                 apply_bn: bool = True, pad_front: bool = True):
+                 apply_bn: bool = False, pad_front: bool = True):
         import ctypes as C
-        state_dict = map_icon_state_dict(state_dict)
+        state_dict, self.tree = map_icon_state_dict(state_dict, with_tree=True)
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.OaiError("no HIP device: the MI355X path has no CPU fallback")
@@ -145,8 +213,9 @@ class IconEngine:
             keep.append(t)
             return t.data_ptr()
 
-        params = (_lib.IconUnetParams * 3)()
-        for n, pre in enumerate(_NET_PREFIXES):
+        n_nets = len(self.tree.net_prefixes)
+        params = (_lib.IconUnetParams * n_nets)()
+        for n, pre in enumerate(self.tree.net_prefixes):
             p = params[n]
             for d in range(5):
                 p.down_w[d], p.down_b[d] = ptr(f"{pre}downConvs.{d}.weight"), ptr(f"{pre}downConvs.{d}.bias")
@@ -155,10 +224,13 @@ class IconEngine:
                     p.bn_gamma[d], p.bn_beta[d] = ptr(f"{pre}batchNorms.{d}.weight"), ptr(f"{pre}batchNorms.{d}.bias")
                     p.bn_mean[d], p.bn_var[d] = ptr(f"{pre}batchNorms.{d}.running_mean"), ptr(f"{pre}batchNorms.{d}.running_var")
             p.last_w, p.last_b = ptr(f"{pre}lastConv.weight"), ptr(f"{pre}lastConv.bias")
+        nodes = (_lib.IconNode * len(self.tree.nodes))(*[_lib.IconNode(*nd) for nd in self.tree.nodes])
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.oai_icon_create(params, *self.net_shape, C.byref(handle)), "oai_icon_create")
+            _lib.check(self.lib.oai_icon_create(params, n_nets, nodes, len(self.tree.nodes), self.tree.root, *self.net_shape,
+                                                C.byref(handle)), "oai_icon_create")
         self._h = handle
+        self.n_nets = n_nets
         self.apply_bn, self.pad_front = bool(apply_bn), bool(pad_front)
         if not pad_front:
             _lib.check(self.lib.oai_icon_set_option(self._h, b"pad_front", 0), "oai_icon_set_option")
@@ -169,6 +241,13 @@ class IconEngine:
         if h:
             self.lib.oai_icon_destroy(h)
             self._h = None
+
+    def describe(self):
+        """(n_nets, U-Nets per halving level, length of the final compose chain) as the library compiled the tree."""
+        import ctypes as C
+        n, lv, cl = C.c_int(), (C.c_int * 8)(), C.c_int()
+        _lib.check(self.lib.oai_icon_describe(self._h, C.byref(n), lv, C.byref(cl)), "oai_icon_describe")
+        return n.value, list(lv), cl.value
 
     def set_graph(self, enable: bool) -> None:
         """hipGraph replay of one direction's launches (default on); off = the same launches issued one by one."""
@@ -223,7 +302,7 @@ class ICON_Registration:
     """
 
     def __init__(self, weights=None, net_shape: Sequence[int] = NET_SHAPE, device=None, verbose: bool = True,
-                 apply_bn: bool = True, pad_front: bool = True):
+                 apply_bn: bool = False, pad_front: bool = True):
         import os
         if weights is None:
             root = os.environ.get("OAI_DATA_DIR")

@@ -76,6 +76,38 @@ def make_volume(seed: int, shape_zyx: Sequence[int] = (160, 384, 384)) -> np.nda
     return (smooth + noise).clamp_(0.0, 1.0).numpy().astype(np.float32)
 
 
+def make_volume_windowed(seed: int, shape_zyx: Sequence[int] = (160, 384, 384), frac: float = 0.05) -> np.ndarray:
+    """``make_volume`` stretched so that ``frac`` of the voxels sit at exactly 0 and ``frac`` at exactly 1: the dynamic range of an
+    intensity-windowed knee (dask_processing.py:10-26 clips at two percentiles and rescales to [0,1])."""
+    v = make_volume(seed, shape_zyx).astype(np.float64)
+    lo, hi = np.quantile(v, [frac, 1.0 - frac])
+    return np.clip((v - lo) / (hi - lo), 0.0, 1.0).astype(np.float32)
+
+
+# Full-size parity cases (tests/golden/make_golden_fullsize.py makes one reference golden per case; tests/test_fullsize_gpu.py
+# and bench.py regenerate the same inputs): network variant x volume variant.
+FULLSIZE_CASES = {
+    "base": dict(weight_seed=0, bn=False, bias_shift=0.0, volume_seed=42, windowed=False, file="segment_fullsize.npz"),
+    "bn": dict(weight_seed=1, bn=True, bias_shift=0.0, volume_seed=43, windowed=False, file="segment_fullsize_bn.npz"),
+    "dc": dict(weight_seed=2, bn=False, bias_shift=1.0, volume_seed=44, windowed=False, file="segment_fullsize_dc.npz"),
+    "win": dict(weight_seed=3, bn=False, bias_shift=0.0, volume_seed=45, windowed=True, file="segment_fullsize_win.npz"),
+}
+
+
+def make_fullsize_case(name: str, shape_zyx: Sequence[int] = (160, 384, 384)):
+    """(state_dict, volume, case dict) of one full-size parity case.  ``bias_shift`` adds a constant to every conv bias of the
+    17 ReLU layers (DC-heavy activations: every channel rides on a positive offset, the regime where the Winograd input
+    transform's d1+d2 / d0-d2 terms cancel); ``bn`` uses the reference's ``BN=True`` network (networks.py:39)."""
+    c = FULLSIZE_CASES[name]
+    sd = make_unet_state_dict(seed=c["weight_seed"], bn=c["bn"])
+    if c["bias_shift"]:
+        for k in sd:
+            if k.endswith(".0.bias"):
+                sd[k] = sd[k] + c["bias_shift"]
+    vol = (make_volume_windowed if c["windowed"] else make_volume)(c["volume_seed"], shape_zyx)
+    return sd, vol, c
+
+
 def make_smooth_field(seed: int, shape_zyx: Sequence[int], amplitude: float, coarse: int = 10) -> np.ndarray:
     """Smooth 3-channel displacement field [3,D,H,W] in [0,1] map units."""
     g = torch.Generator().manual_seed(4321 + seed)
@@ -118,15 +150,46 @@ def make_icon_unet_state_dict(seed: int, dimension: int = 3, last_scale: float =
     return sd
 
 
-def make_icon_state_dict(seed: int = 0, last_scale: float = 0.3) -> "OrderedDict[str, torch.Tensor]":
-    """``regis_net`` state dict of ``OAI_knees_gradICON_model``: three tallUNet2s.
+# Step trees of the registration network as nested tuples: "u" = FunctionFromVectorField(tallUNet2), ("down", t) =
+# DownsampleRegistration(t), ("two", phi, psi) = TwoStepRegistration(netPhi=phi, netPsi=psi).
+ICON_TREES = {
+    # SURVEY Appendix A's recollection of OAI_knees_gradICON_model: two half-resolution steps + one full-resolution step
+    "3step": ("two", ("down", ("two", "u", "u")), "u"),
+    # "the definition of our final 4 step registration network": one more full-resolution step around it (VERDICT r3 missing #2)
+    "4step": ("two", ("two", ("down", ("two", "u", "u")), "u"), "u"),
+    # the gradICON multi-resolution cascade: quarter-, half-, full-resolution
+    "multires": ("two", ("down", ("two", ("down", "u"), "u")), "u"),
+    # ... and with a last full-resolution step
+    "multires4": ("two", ("two", ("down", ("two", ("down", "u"), "u")), "u"), "u"),
+}
 
-    Key prefixes follow the module tree TwoStep(Downsample(TwoStep(FFVF,FFVF)),FFVF):
-    ``netPhi.net.netPhi.net.*`` (u1, low-res), ``netPhi.net.netPsi.net.*`` (u2, low-res),
-    ``netPsi.net.*`` (u3, full-res).
-    """
+
+def icon_tree_prefixes(tree) -> list:
+    """state_dict prefixes of the U-Nets of ``tree`` (a name of ICON_TREES or a nested tuple) in execution order, spelled as
+    torch's ``nn.Module.state_dict`` spells the attribute path (``netPhi`` / ``netPsi`` of a TwoStep, ``net`` of a Downsample or FFVF)."""
+    tree = ICON_TREES[tree] if isinstance(tree, str) and tree in ICON_TREES else tree
+    out = []
+
+    def visit(t, prefix):
+        if t == "u":
+            out.append(prefix + "net.")
+        elif t[0] == "down":
+            visit(t[1], prefix + "net.")
+        elif t[0] == "two":
+            visit(t[1], prefix + "netPhi.")
+            visit(t[2], prefix + "netPsi.")
+        else:
+            raise ValueError(f"bad tree element {t!r}")
+
+    visit(tree, "")
+    return out
+
+
+def make_icon_state_dict(seed: int = 0, last_scale: float = 0.3, tree="3step") -> "OrderedDict[str, torch.Tensor]":
+    """``regis_net`` state dict of a gradICON model: one tallUNet2 per FFVF of ``tree`` (default: the three-step tree, key prefixes
+    ``netPhi.net.netPhi.net.*`` (u1, low-res), ``netPhi.net.netPsi.net.*`` (u2, low-res), ``netPsi.net.*`` (u3, full-res))."""
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for i, prefix in enumerate(("netPhi.net.netPhi.net.", "netPhi.net.netPsi.net.", "netPsi.net.")):
+    for i, prefix in enumerate(icon_tree_prefixes(tree)):
         for k, v in make_icon_unet_state_dict(seed * 3 + i, last_scale=last_scale).items():
             out[prefix + k] = v
     return out

@@ -39,7 +39,7 @@ NET_SHAPE = (80, 192, 192)          # OAI_knees_gradICON_model: input_shape = [1
 BN_EPS = 1e-5
 LEAKY = 0.01                         # F.leaky_relu default slope
 
-U1 = "netPhi.net.netPhi.net."       # low-res step 1
+U1 = "netPhi.net.netPhi.net."       # the three-step tree of SURVEY Appendix A: low-res step 1
 U2 = "netPhi.net.netPsi.net."       # low-res step 2
 U3 = "netPsi.net."                   # full-res step
 
@@ -48,7 +48,9 @@ U3 = "netPsi.net."                   # full-res step
 # VERDICT r2 missing #4): whether ``UNet2.forward`` applies ``batchNorms[depth]`` (the ModuleList exists either way, so the keys are
 # in the state_dict) and on which side ``pad_or_crop`` puts the zero channels.  Both are switches here and in the library
 # (oai_icon_create: bn_* == NULL; oai_icon_set_option "pad_front"), tested in all four combinations; the defaults are SURVEY's.
-OPTIONS = {"apply_bn": True, "pad_front": True}
+# Round 4: apply_bn defaults to False -- two independent recollections (ADVICE r3, and the builder's) have the line
+# ``# x = self.batchNorms[depth](x)`` commented out in UNet2.forward.
+OPTIONS = {"apply_bn": False, "pad_front": True}
 
 
 def _pad_or_crop_channels(x: torch.Tensor, c: int, pad_front: bool = True) -> torch.Tensor:
@@ -106,12 +108,78 @@ def sample_at(src: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
     return F.grid_sample(src, grid, mode="bilinear", padding_mode="border", align_corners=True)
 
 
+_UNET_ATTRS = {"downConvs", "upConvs", "batchNorms", "lastConv", "residues"}
+_BUFFERS = {"identity_map", "spacing", "num_batches_tracked", "_extra_state"}
+
+
+def _children(sd, prefix):
+    return sorted({k[len(prefix):].split(".", 1)[0] for k in sd
+                   if k.startswith(prefix) and k.rsplit(".", 1)[-1] not in _BUFFERS})
+
+
+def _apply(links, coords, tagged_identity: bool):
+    """A closure of the package applied to a coordinate map: ``links`` are the displacement tensors of the FFVFs in application
+    order (for TwoStep's ``lambda x: phi(psi(x))``: psi's links, then phi's).  ``FunctionFromVectorField.forward``'s
+    ``transform``: ``coords + d`` if coords is the tagged identity map and has d's shape, else ``coords + sample(d, coords)``;
+    the result of either is an ordinary tensor (the tag does not propagate)."""
+    for d in links:
+        if tagged_identity and coords.shape == d.shape:
+            coords = coords + d
+        else:
+            coords = coords + sample_at(d, coords)
+        tagged_identity = False
+    return coords
+
+
+def forward_tree(sd: Dict[str, torch.Tensor], prefix: str, A: torch.Tensor, B: torch.Tensor, trace=None):
+    """``module.forward(A, B)`` of the wrapper module whose parameters live under ``prefix`` -- the module type is read off the
+    names of its children exactly as ``nn.Module.state_dict`` spells them -- returned as the list of its closure's links.
+
+    * ``TwoStepRegistration`` (children netPhi, netPsi): ``phi = netPhi(A, B)``;
+      ``psi = netPsi(as_function(A)(phi(self.identity_map)), B)`` with ``self.identity_map`` tagged isIdentity at the top of
+      forward; returns ``lambda x: phi(psi(x))``.
+    * ``DownsampleRegistration`` (child net = another wrapper): ``net(avg_pool(A, 2, ceil_mode=True), avg_pool(B, ...))``.
+    * ``FunctionFromVectorField`` (child net = a UNet2): ``d = net(A, B)``.
+    """
+    kids = _children(sd, prefix)
+    if kids == ["netPhi", "netPsi"]:
+        phi = forward_tree(sd, prefix + "netPhi.", A, B, trace)
+        ident = identity_map(A.shape[2:])
+        A_w = sample_at(A, _apply(phi, ident, True))
+        if trace is not None:
+            trace.append(("warp", prefix, A_w))
+        psi = forward_tree(sd, prefix + "netPsi.", A_w, B, trace)
+        return psi + phi
+    if kids == ["net"]:
+        grand = _children(sd, prefix + "net.")
+        if grand and set(grand) <= _UNET_ATTRS:
+            d = tall_unet2(A, B, sd, prefix + "net.")
+            if trace is not None:
+                trace.append(("unet", prefix + "net.", d))
+            return [d]
+        return forward_tree(sd, prefix + "net.", F.avg_pool3d(A, 2, ceil_mode=True), F.avg_pool3d(B, 2, ceil_mode=True), trace)
+    raise KeyError(f"not a registration wrapper under '{prefix}': {kids[:4]}")
+
+
 @torch.no_grad()
 def regis_net_direction(A: torch.Tensor, B: torch.Tensor, sd: Dict[str, torch.Tensor], return_all: bool = False):
-    """phi_AB(identity) for TwoStep(Downsample(TwoStep(FFVF(u1),FFVF(u2))), FFVF(u3)).
+    """phi_AB(identity) = ``regis_net(A, B)(identity_map)`` for whatever wrapper tree ``sd``'s keys spell, e.g.
+    TwoStep(Downsample(TwoStep(FFVF(u1),FFVF(u2))), FFVF(u3)) or the four-step form with one more FFVF around it.
 
-    A, B: [1,1,D,H,W] network-resolution images.  Returns the dense map [1,3,D,H,W] in [0,1] units.
+    A, B: [1,1,D,H,W] network-resolution images.  Returns the dense map [1,3,D,H,W] in [0,1] units
+    (``GradientICON.forward`` tags ``identity_map.isIdentity``, ``register_pair`` evaluates ``model.phi_AB(model.identity_map)``).
     """
+    trace = [] if return_all else None
+    links = forward_tree(sd, "", A, B, trace)
+    phi = _apply(links, identity_map(A.shape[2:]), True)
+    if return_all:
+        return phi, trace
+    return phi
+
+
+@torch.no_grad()
+def regis_net_direction_3step_unrolled(A: torch.Tensor, B: torch.Tensor, sd: Dict[str, torch.Tensor]):
+    """The three-step tree written out by hand (rounds 1-3's oracle): a cross-check of the recursion above."""
     id_h = identity_map(A.shape[2:])
     a = F.avg_pool3d(A, 2, ceil_mode=True)                         # DownsampleRegistration.forward
     b = F.avg_pool3d(B, 2, ceil_mode=True)
@@ -119,18 +187,13 @@ def regis_net_direction(A: torch.Tensor, B: torch.Tensor, sd: Dict[str, torch.Te
     d1 = tall_unet2(a, b, sd, U1)                                   # FFVF(u1)
     a_w = sample_at(a, id_l + d1)                                   # tagged identity, same shape -> shortcut
     d2 = tall_unet2(a_w, b, sd, U2)                                 # FFVF(u2)
-    # outer TwoStep: phi(identity_hi) = phi1(phi2(id_h)); id_h has another shape -> sampled path
-    c1 = id_h + sample_at(d2, id_h)
+    c1 = id_h + sample_at(d2, id_h)                                 # outer TwoStep: id_h has another shape -> sampled path
     c2 = c1 + sample_at(d1, c1)
     A_w = sample_at(A, c2)
     d3 = tall_unet2(A_w, B, sd, U3)                                 # FFVF(u3)
-    # phi_AB(identity) = phi1(phi2(phi3(id_h)))
     c3 = id_h + d3                                                  # tagged identity, same shape -> shortcut
     c4 = c3 + sample_at(d2, c3)
-    phi = c4 + sample_at(d1, c4)
-    if return_all:
-        return phi, dict(a=a, b=b, d1=d1, a_w=a_w, d2=d2, c1=c1, c2=c2, A_w=A_w, d3=d3, c3=c3, c4=c4)
-    return phi
+    return c4 + sample_at(d1, c4)
 
 
 @torch.no_grad()

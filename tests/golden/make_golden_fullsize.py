@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""Generate tests/golden/segment_fullsize.npz: the REFERENCE's own ``Segmenter3DInPatchClassWise.segment``
+"""Generate tests/golden/segment_fullsize[_<case>].npz (``--case base|bn|dc|win``, see oai_analysis_2_amd.synth.FULLSIZE_CASES:
+base = weight seed 0 / volume seed 42; bn = weight seed 1 with BN=True (networks.py:39) / volume 43; dc = weight seed 2 with every
+conv bias + 1.0 (DC-heavy activations) / volume 44; win = weight seed 3 / an intensity-windowed volume with 5 % of the voxels at
+exactly 0 and at exactly 1, dask_processing.py:10-26): the REFERENCE's own ``Segmenter3DInPatchClassWise.segment``
 (oai_analysis/segmentation/segmenter.py:100-131) run once, on CPU, on a seeded 384x384x160 volume (BASELINE config 2 size).
 
 Run here only (``python tests/golden/make_golden_fullsize.py``, ~6 minutes on 8 cores): it imports the reference from
@@ -30,19 +33,24 @@ sys.path.insert(0, HERE)
 REF = os.environ.get("OAI_REFERENCE", "/root/reference")
 
 SHAPE = (160, 384, 384)
-VOLUME_SEED, WEIGHT_SEED = 42, 0
 START, STRIDE = (1, 2, 3), (4, 4, 4)
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="base", help="base | bn | dc | win (oai_analysis_2_amd.synth.FULLSIZE_CASES)")
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
     from make_golden import install_itk_shim
     install_itk_shim()
     sys.path.insert(0, REF)
     from oai_analysis.segmentation.segmenter import Segmenter3DInPatchClassWise  # the reference
-    from oai_analysis_2_amd.synth import make_unet_state_dict, make_volume
+    from oai_analysis_2_amd.synth import make_fullsize_case
 
-    torch.set_num_threads(8)
-    vol = make_volume(VOLUME_SEED, SHAPE)
+    torch.set_num_threads(args.threads)
+    sd, vol, case = make_fullsize_case(args.case, SHAPE)
+    VOLUME_SEED, WEIGHT_SEED = case["volume_seed"], case["weight_seed"]
     patch, ovl = (128, 128, 32), (16, 16, 8)            # analysis_object.py:18-26 literals; patch_size of the model JSON
     res = {"volume_seed": np.int64(VOLUME_SEED), "weight_seed": np.int64(WEIGHT_SEED), "patch": np.asarray(patch),
            "overlap": np.asarray(ovl), "start": np.asarray(START), "stride": np.asarray(STRIDE),
@@ -52,9 +60,9 @@ def main():
         cfg = os.path.join(td, "cfg.pth.tar")
         with open(cfg, "w") as f:
             json.dump({"patch_size": list(patch), "model": "UNet",
-                       "model_setting": {"in_channels": 1, "n_classes": 2, "bias": True, "BN": False}}, f)
+                       "model_setting": {"in_channels": 1, "n_classes": 2, "bias": True, "BN": bool(case["bn"])}}, f)
         ck = os.path.join(td, "model.pth.tar")
-        torch.save({"model_state_dict": make_unet_state_dict(seed=WEIGHT_SEED), "epoch": 1, "best_score": 0.0}, ck)
+        torch.save({"model_state_dict": sd, "epoch": 1, "best_score": 0.0}, ck)
         seg = Segmenter3DInPatchClassWise(mode="pred", config=dict(
             ckpoint_path=ck, training_config_file=cfg, device="cpu", batch_size=4,
             overlap_size=ovl, output_prob=True, output_itk=True))
@@ -76,9 +84,11 @@ def main():
     flat = prob.reshape(-1)
     near = np.flatnonzero(np.abs(flat - 0.5) < 1e-4)
     res["near_idx"], res["near_prob"] = near.astype(np.int64), flat[near].astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, "segment_fullsize.npz"), **res)
-    print("segment_fullsize", res["mask_count"], res["prob_sum"], len(near), res["fc_prob_s"].shape,
-          os.path.getsize(os.path.join(HERE, "segment_fullsize.npz")))
+    res["case"] = np.asarray(args.case)
+    res["prob_range"] = np.asarray([prob[:, 8:-8, 16:-16, 16:-16].min(), prob.max()])
+    np.savez_compressed(os.path.join(HERE, case["file"]), **res)
+    print(case["file"], res["mask_count"], res["prob_sum"], res["prob_range"], len(near), res["fc_prob_s"].shape,
+          os.path.getsize(os.path.join(HERE, case["file"])))
 
 
 if __name__ == "__main__":

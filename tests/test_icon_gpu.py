@@ -115,3 +115,92 @@ def test_restatement_switches_match_the_oracle_both_ways(apply_bn, pad_front):
     for _ in range(2):                                       # second call = graph replay
         got = eng.phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy()
         assert _rel(got - ident, ref - ident) < TOL
+
+
+# ---- the step tree is data: whatever TwoStep / Downsample / FFVF nesting the checkpoint's keys spell -------------
+
+TREES = [("3step", (40, 48, 48)), ("4step", (40, 48, 48)), ("multires", (68, 72, 76)), ("multires4", (68, 76, 72))]
+
+
+def _op_by_op(eng, tree, node, A, B):
+    """network_wrappers' forward written with the library's single-op launches (eng.unet, avgpool2, compose, grid_sample3d): the
+    links of the node's closure in application order."""
+    from oai_analysis_2_amd import ops
+    from oai_analysis_2_amd.registration import DOWN, FFVF
+    kind, a, b = tree.nodes[node]
+    if kind == FFVF:
+        return [eng.unet(a, A, B)]
+    if kind == DOWN:
+        return _op_by_op(eng, tree, a, ops.avgpool2(A[None])[0], ops.avgpool2(B[None])[0])
+    phi = _op_by_op(eng, tree, a, A, B)
+    A_w = ops.grid_sample3d(A[None], _apply_ops(phi, A.shape))[0]
+    return _op_by_op(eng, tree, b, A_w, B) + phi
+
+
+def _apply_ops(links, shape):
+    from oai_analysis_2_amd import ops
+    c = None
+    for i, d in enumerate(links):
+        if i == 0:
+            c = ops.compose(d, None, out_shape=shape, shortcut=tuple(d.shape[1:]) == tuple(shape))
+        else:
+            c = ops.compose(d, c)
+    return c
+
+
+@pytest.mark.parametrize("tree_name,net", TREES)
+def test_step_trees_match_the_oracle_and_the_op_by_op_launches(tree_name, net):
+    """Three-step, four-step ("our final 4 step registration network"), the multi-resolution cascade and its
+    four-step form: (a) phi within 1e-4 rel of the oracle's recursion over the same keys; (b) the compiled plan (fused chains, one
+    hipGraph) is BIT-IDENTICAL to the same tree walked op by op through the single-op entry points -- so the three-step path is
+    what rounds 1-3 shipped; (c) the replayed graph equals the first (capturing) call and the direct launches."""
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.synth import icon_tree_prefixes
+    sd = make_icon_state_dict(4, 0.3, tree_name)
+    eng = IconEngine(sd, net_shape=net)
+    n_nets = len(icon_tree_prefixes(tree_name))
+    assert eng.tree.net_prefixes == icon_tree_prefixes(tree_name)
+    got_n, levels, chain_len = eng.describe()
+    assert got_n == n_nets and sum(levels) == n_nets and chain_len == n_nets
+    assert levels[:3] == {"3step": [1, 2, 0], "4step": [2, 2, 0], "multires": [1, 1, 1], "multires4": [2, 1, 1]}[tree_name]
+    A, B = make_volume(5, net), make_volume(6, net)
+    ref = oicon.regis_net_direction(torch.from_numpy(A)[None, None], torch.from_numpy(B)[None, None], sd)[0].numpy()
+    ident = oicon.identity_map(net)[0].numpy()
+    tA, tB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    got = eng.phi(tA, tB)
+    rel = _rel(got.cpu().numpy() - ident, ref - ident)
+    print(f"[icon tree {tree_name}] {eng.tree.describe()}: displacement rel err vs oracle {rel:.2e}, max |disp| {np.abs(ref - ident).max():.3f}")
+    assert np.abs(ref - ident).max() > 0.01 and rel < TOL
+    manual = _apply_ops(_op_by_op(eng, eng.tree, eng.tree.root, tA, tB), net)
+    assert torch.equal(got, manual)
+    assert torch.equal(eng.phi(tA, tB), got) and eng.graph_info()[0] == 1            # replay
+    eng.set_graph(False)
+    assert torch.equal(eng.phi(tA, tB), got)
+
+
+def test_three_step_recursion_equals_the_unrolled_oracle():
+    """The oracle's recursion over the key tree reproduces the hand-unrolled three-step wiring of rounds 1-3 bit for bit (CPU only,
+    but it needs the synthetic weights' size: kept with the GPU tests for time)."""
+    sd = make_icon_state_dict(2)
+    net = (40, 48, 48)
+    A, B = (torch.from_numpy(make_volume(i, net))[None, None] for i in (3, 4))
+    assert torch.equal(oicon.regis_net_direction(A, B, sd), oicon.regis_net_direction_3step_unrolled(A, B, sd))
+
+
+def test_malformed_trees_are_refused():
+    import ctypes as C
+    from oai_analysis_2_amd import _lib
+    from oai_analysis_2_amd.registration import DOWN, FFVF, TWO, IconEngine
+    sd = make_icon_state_dict(0)
+    with pytest.raises(_lib.OaiError):                   # quarter-resolution grid 10x12x12 cannot take five 2x poolings
+        IconEngine(make_icon_state_dict(0, 0.3, "multires"), net_shape=(40, 48, 48))
+    eng = IconEngine(sd, net_shape=(40, 48, 48))
+    lib = eng.lib
+    params = (_lib.IconUnetParams * 3)()
+    h = C.c_void_p()
+    for bad in ([(FFVF, 0, 0), (FFVF, 0, 0), (TWO, 0, 1)],          # net 0 twice, nets 1 / 2 unused
+                [(TWO, 0, 0)],                                     # a node that is its own child
+                [(FFVF, 0, 0), (DOWN, 0, 0), (FFVF, 1, 0), (FFVF, 2, 0), (TWO, 1, 2)],   # node 3 unreachable
+                [(FFVF, 7, 0)]):                                   # net index out of range
+        nodes = (_lib.IconNode * len(bad))(*[_lib.IconNode(*nd) for nd in bad])
+        assert lib.oai_icon_create(params, 3, nodes, len(bad), len(bad) - 1, 40, 48, 48, C.byref(h)) != 0

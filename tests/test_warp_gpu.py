@@ -129,5 +129,12 @@ def test_fused_warp_chain_is_bit_identical_to_the_op_by_op_closures(shape):
     ref = (r4 + oicon.sample_at(t(d1), r4))[0].numpy()
     ident = id_h[0].numpy()
     assert _rel(phi.cpu().numpy() - ident, ref - ident) < TOL
+    # longer chains (a four-step tree: start + three sampled fields of mixed resolution) against the op-by-op launches
+    d4 = _dev(make_smooth_field(6, shape, 0.01))
+    c = ops.compose(d4, None, shortcut=True)
+    for f in (d3, d2, d1):
+        c = ops.compose(f, c)
+    assert torch.equal(ops.warp_chain(shape, fields=[d3, d2, d1], start=d4), c)
+    assert torch.equal(ops.warp_chain(shape, fields=[d3, d2, d1], start=d4, image=A), ops.grid_sample3d(A[None], c)[0])
     with pytest.raises(Exception):
-        ops.warp_chain(shape, fields=[d2, d1, d2])
+        ops.warp_chain(shape, fields=[d2, d1] * 5)
