@@ -117,20 +117,21 @@ def cpu_baseline(vol_np, meta_A, atlas_img, unet_sd, icon_sd, n_tiles_sample=8, 
                       f"(x{2 * atlas_img.array.shape[0] // zs}); s/tile={t_tile:.2f} s_register={t_reg:.1f} s_resample={t_res:.1f}; torch threads = physical cores"}
 
 
-def fullsize_parity(unet, precision):
-    """The segmentation of the golden volume in `precision` against tests/golden/segment_fullsize.npz -- the REFERENCE's own
-    segment() run on CPU at 384x384x160 (tests/golden/make_golden_fullsize.py).  Data fixture, not the oracle; outside the
-    timed region.  The same comparison is asserted by tests/test_fullsize_gpu.py."""
+def fullsize_parity(unet, precision, case="base"):
+    """The segmentation of a golden volume in `precision` against tests/golden/segment_fullsize[_<case>].npz -- the REFERENCE's own
+    segment() run on CPU at 384x384x160 (tests/golden/make_golden_fullsize.py --case ...; `unet` must hold that case's network).
+    Data fixture, not the oracle; outside the timed region.  The same comparison is asserted by tests/test_fullsize_gpu.py."""
     import hashlib
     import numpy as np
     import torch
     from oai_analysis_2_amd.pipeline import CROP_ZYX, OVERLAP_ZYX, TILE_ZYX
-    from oai_analysis_2_amd.synth import make_volume
-    path = os.path.join(ROOT, "tests", "golden", "segment_fullsize.npz")
+    from oai_analysis_2_amd.synth import FULLSIZE_CASES, make_volume, make_volume_windowed
+    c = FULLSIZE_CASES[case]
+    path = os.path.join(ROOT, "tests", "golden", c["file"])
     if not os.path.exists(path):
         return None
     z = np.load(path)
-    vol = make_volume(int(z["volume_seed"]), VOL_SHAPE)
+    vol = (make_volume_windowed if c["windowed"] else make_volume)(int(z["volume_seed"]), VOL_SHAPE)
     same_input = hashlib.sha256(vol.tobytes()).digest() == bytes(z["volume_sha256"])
     prev = unet.precision
     unet.set_precision(precision)
@@ -148,12 +149,63 @@ def fullsize_parity(unet, precision):
     got_s = np.stack([prob[0][sl], prob[1][sl]]).astype(np.float64)
     dsum = np.abs(got_s - ref_s).sum(axis=(1, 2, 3))
     scale = vol.size / ref_s[0].size
-    return {"against": "tests/golden/segment_fullsize.npz = the reference's Segmenter3DInPatchClassWise.segment on CPU, 384x384x160, seeded weights",
+    return {"against": f"tests/golden/{c['file']} = the reference's Segmenter3DInPatchClassWise.segment on CPU, 384x384x160, seeded weights",
             "precision": precision, "input_bit_identical": bool(same_input), "mask_voxels": int(2 * vol.size),
             "mask_flips": int(len(flips)), "max_abs_pref_minus_half_at_flips": float(worst),
             "flips_with_pref_farther_than_1e-5_from_half": int(sum(1 for i in flips if abs(near.get(int(i), 0.0) - 0.5) >= 1e-5)),
             "sum_abs_dp_per_23.6M_voxels": [float(d * scale) for d in dsum], "reference_budget_sum_abs_dp": 12.0,
             "max_abs_dp_sample": float(np.abs(got_s - ref_s).max()), "sample_voxels_per_map": int(ref_s[0].size)}
+
+
+def other_cases_parity(precision):
+    """the same comparison on three more reference runs (other weight seeds, BN=True, DC-heavy activations, an
+    intensity-windowed input; oai_analysis_2_amd.synth.FULLSIZE_CASES), each with its own engine and calibration; compact."""
+    import torch
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    from oai_analysis_2_amd.synth import make_fullsize_case
+    out = {}
+    try:                                                           # the reference's OWN fp32-vs-fp64 distance per network (tests/golden/make_golden_truth.py)
+        import numpy as np
+        truth = np.load(os.path.join(ROOT, "tests", "golden", "segment_fullsize_truth.npz"))
+    except OSError:
+        truth = None
+    for case in ("bn", "dc", "win"):
+        sd, _, c = make_fullsize_case(case, (8, 8, 8))             # (the volume is regenerated at full size inside fullsize_parity)
+        eng = UNetEngine(sd, precision=precision)
+        r = fullsize_parity(eng, precision, case)
+        if r is not None:
+            out[case] = {"network": f"weight seed {c['weight_seed']}, BN={c['bn']}, bias shift {c['bias_shift']}",
+                         "volume": f"seed {c['volume_seed']}" + (", 5 % of the voxels at exactly 0 and at exactly 1" if c["windowed"] else ""),
+                         "input_bit_identical": r["input_bit_identical"], "mask_flips": r["mask_flips"],
+                         "flips_with_pref_farther_than_1e-5_from_half": r["flips_with_pref_farther_than_1e-5_from_half"],
+                         "sum_abs_dp_per_23.6M_voxels": r["sum_abs_dp_per_23.6M_voxels"], "max_abs_dp_sample": r["max_abs_dp_sample"],
+                         "reference_own_fp32_noise_sum_abs_dp": truth[f"{case}_ref_err"].tolist() if truth is not None else None,
+                         "range_flag": eng.range_flag() if precision == "fp16x3" else 0}
+        eng._ws = None
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
+def icon_step_tree_times(A, B):
+    """Device time of one registration direction at 80x192x192 for the step trees a checkpoint's keys may spell:
+    today's three steps and the four-step form with a second full-resolution U-Net.  Outside the timed region."""
+    import torch
+    from oai_analysis_2_amd.registration import IconEngine
+    from oai_analysis_2_amd.synth import make_icon_state_dict
+    out = {}
+    for tree in ("3step", "4step"):
+        eng = IconEngine(make_icon_state_dict(0, 0.1, tree))
+        for _ in range(2):
+            eng.phi(A, B)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            eng.phi(A, B)
+        e1.record()
+        torch.cuda.synchronize()
+        out[tree] = {"tree": eng.tree.describe(), "ms_per_direction": e0.elapsed_time(e1) / 10}
+    return out
 
 
 def rescaled_network_parity(unet_sd):
@@ -297,7 +349,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive leg (8 volumes streamed from host memory, BASELINE config 4)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="result-preserving tuning option of the fp16x3 path (oai_unet_set_option: sres, sres_mrep, sres_ring, xcd_group); repeatable")
+                    help="tuning option of the fp16x3 path (oai_unet_set_option, include/oai_hip.h); bit-preserving: sres, sres_mrep, sres_ring, "
+                         "xcd_group, fuse_first, b_lds, wide, shared_enc, dead_stores, census; NOT bit-preserving: winograd (bit mask, default 3; "
+                         "0 = direct form), winograd_layers; repeatable")
     ap.add_argument("--no-overlap", action="store_true", help="registration after, not underneath, the segmentation (A/B of VolumePipeline.overlap_registration)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of launcher + collectives, no GPU, no kernels")
     args = ap.parse_args()
@@ -487,8 +541,22 @@ def main():
         }
         if world == 1 and not args.no_parity:
             out["parity"] = fullsize_parity(unet, args.precision)
-            if args.precision == "fp16x3" and out["parity"] is not None:
-                out["parity"]["rescaled_network"] = rescaled_network_parity(unet_sd)
+            if out["parity"] is not None:
+                if args.precision == "fp16x3":
+                    out["parity"]["rescaled_network"] = rescaled_network_parity(unet_sd)
+                others = out["parity"]["other_cases"] = other_cases_parity(args.precision)
+                # the headline arithmetic's own parity numbers in <= 200 bytes, inside `config`: flips and the larger
+                # class's sum|dp| per 23.6 M voxels (reference budget 12) for base / bn / dc / win
+                rows = [out["parity"]] + [others[k] for k in ("bn", "dc", "win") if k in others]
+                out["config"]["parity_headline"] = {"precision": args.precision + ("+winograd" if args.precision == "fp16x3" and "winograd=0" not in args.option else ""),
+                                                    "cases": ["base", "bn", "dc", "win"][:len(rows)],
+                                                    "flips": [r["mask_flips"] for r in rows],
+                                                    "sum_abs_dp": [round(max(r["sum_abs_dp_per_23.6M_voxels"]), 2) for r in rows],
+                                                    "budget": "max(12, 3x ref fp32 noise)"}
+        if world == 1 and not args.no_parity:
+            A_net = torch.from_numpy(make_volume(1, (80, 192, 192))).cuda()
+            B_net = torch.from_numpy(make_volume(2, (80, 192, 192))).cuda()
+            out["registration_step_trees"] = icon_step_tree_times(A_net, B_net)
         if world == 1 and not args.no_streamed and args.mode == "replicas":
             out["streamed_from_host"] = streamed_from_host(pipe)
         if world == 1 and not args.no_alt:

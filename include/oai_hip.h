@@ -176,6 +176,14 @@ int oai_unet_range_flag(oai_unet* h, int reset, int* out, void* stream);
  * queued on `stream` behind the segment calls of ONE volume, so the flag is attributed to that volume; the caller reads
  * dst_dev with its own D2H copy of the results.  No synchronisation. */
 int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream);
+/* The same snapshot as RAW STATE for a volume whose tiles were computed by several ranks (pipeline.run_sharded): state_dev[0] = the
+ * overflow bit, state_dev[1 + k] = the bits of layer k's largest stored activation (a non-negative float: ordered like its integer
+ * bits), so that an elementwise MAX all-reduce over the ranks gives the state of the WHOLE volume -- a rank that holds only quiet
+ * background tiles must not raise the LOW bit on its own subset.  Clears flag and census like the snapshot.
+ * oai_unet_range_flag_from_state evaluates a (reduced) state into the two-bit flag word, flag_dev[0]. */
+#define OAI_UNET_RANGE_STATE_WORDS (1 + OAI_UNET_NUM_LAYERS)
+int oai_unet_range_state_snapshot(oai_unet* h, int* state_dev, void* stream);
+int oai_unet_range_flag_from_state(const int* state_dev, int* flag_dev, void* stream);
 /* Per-layer activation exponents of OAI_PREC_FP16X3.  Layer k (order of OAI_UNET_NUM_LAYERS) stores its output as
  * x * 2^e[k] in fp16 term pairs; powers of two fold exactly into the epilogue affine of the producer, the epilogue scale of
  * the consumer and -- for the skip inputs of dc8 / dc5 / dc2 -- the weight panel, so results change only where fp16's

@@ -70,6 +70,8 @@ SIGNATURES = {
     "oai_unet_set_precision": (_I, [_P, _I]),
     "oai_unet_range_flag": (_I, [_P, _I, C.POINTER(_I), _P]),
     "oai_unet_range_flag_snapshot": (_I, [_P, _P, _P]),
+    "oai_unet_range_state_snapshot": (_I, [_P, _P, _P]),
+    "oai_unet_range_flag_from_state": (_I, [_P, _P, _P]),
     "oai_unet_census": (_I, [_P, C.POINTER(_F), _I, _P]),
     "oai_unet_calibrate_step": (_I, [_P, _P, C.POINTER(_I)]),
     "oai_unet_get_act_exponents": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),

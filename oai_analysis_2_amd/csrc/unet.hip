@@ -978,6 +978,25 @@ __global__ void range_eval_kernel(int* __restrict__ flag, unsigned* __restrict__
         for (int i = 0; i < 16; ++i) census[t * 16 + i] = 0;
 }
 
+// the raw form of range_eval_kernel: [0] = overflow bit, [1 + k] = layer k's maximum (float bits); clears flag and census
+__global__ void range_state_kernel(int* __restrict__ flag, unsigned* __restrict__ census, int* __restrict__ dst) {
+    const int t = threadIdx.x;
+    if (t < 18) {
+        unsigned m = 0;
+        for (int i = 0; i < 16; ++i) { m = max(m, census[t * 16 + i]); census[t * 16 + i] = 0; }
+        dst[1 + t] = (int)m;
+    }
+    if (t == 0) { dst[0] = flag[0] & 1; flag[0] = 0; }
+}
+
+__global__ void range_flag_from_state_kernel(const int* __restrict__ state, int* __restrict__ dst, float low) {
+    const int t = threadIdx.x;
+    const unsigned m = t < 17 ? (unsigned)state[1 + t] : 0u;
+    const bool lowhit = t < 17 && m != 0 && __uint_as_float(m) < low;
+    const unsigned long long any = __ballot(lowhit);
+    if (t == 0) dst[0] = (state[0] & 1) | (any ? 2 : 0);
+}
+
 }  // namespace oai
 
 using namespace oai;
@@ -1137,6 +1156,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         h->opt_dead_stores = value;
     } else if (!strcmp(name, "census")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: census must be 0 or 1");
+        // without the census there is no LOW bit in the range flag and nothing to calibrate from: allowed on a calibrated handle only
+        // (A/B timing of the bookkeeping), so that the subnormal low-term loss cannot come back silently
+        OAI_CHECK_ARG(value == 1 || h->calibrated, "oai_unet_set_option: census 0 needs a calibrated handle (activation exponents set)");
         h->opt_census = value;
     } else if (!strcmp(name, "fuse_first")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: fuse_first must be 0 or 1");
@@ -1166,6 +1188,20 @@ int oai_unet_range_flag_snapshot(oai_unet* h, int* dst_dev, void* stream) {
     OAI_CHECK_ARG(h && dst_dev, "oai_unet_range_flag_snapshot: null pointer");
     hipStream_t st = (hipStream_t)stream;
     range_eval_kernel<<<1, 64, 0, st>>>(h->range_flag, h->census, dst_dev, 1, kLowRange);   // a kernel: stream-ordered with the conv launches around it
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+int oai_unet_range_state_snapshot(oai_unet* h, int* state_dev, void* stream) {
+    OAI_CHECK_ARG(h && state_dev, "oai_unet_range_state_snapshot: null pointer");
+    range_state_kernel<<<1, 64, 0, (hipStream_t)stream>>>(h->range_flag, h->census, state_dev);
+    OAI_CHECK_LAUNCH();
+    return OAI_OK;
+}
+
+int oai_unet_range_flag_from_state(const int* state_dev, int* flag_dev, void* stream) {
+    OAI_CHECK_ARG(state_dev && flag_dev, "oai_unet_range_flag_from_state: null pointer");
+    range_flag_from_state_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state_dev, flag_dev, kLowRange);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
@@ -1216,11 +1252,12 @@ int oai_unet_calibrate_step(oai_unet* h, void* stream, int* more) {
     OAI_CHECK_ARG(h->precision == OAI_PREC_FP16X3, "oai_unet_calibrate_step: the activation exponents belong to OAI_PREC_FP16X3");
     float mx[18];
     if (int rc = oai_unet_census(h, mx, 1, stream)) return rc;
-    int e[18], changed = 0;
+    int e[18], changed = 0, reported = 0;
     for (int k = 0; k < 18; ++k) e[k] = h->act_exp[k];
     for (int k = 0; k < 17; ++k) {
         if (!(mx[k] > 0.0f)) continue;                   // nothing stored (layer not run by the split-resident kernels, or all zero): keep
-        if (!std::isfinite(mx[k])) { e[k] -= 32; changed = 1; continue; }
+        ++reported;
+        if (!std::isfinite(mx[k])) { e[k] = e[k] - 32 < -100 ? -100 : e[k] - 32; changed = 1; continue; }
         int b;
         frexpf(mx[k], &b);                               // mx = m 2^b, m in [0.5, 1): mx in [2^(b-1), 2^b)
         if (b - 1 >= kTargetExp - 1 && b - 1 <= kTargetExp + 1) continue;       // inside [2^9, 2^12): leave it (a verify pass ends here)
@@ -1230,8 +1267,15 @@ int oai_unet_calibrate_step(oai_unet* h, void* stream, int* more) {
         changed = 1;
     }
     *more = changed;
+    // a census that holds nothing (option census 0 / sres 0 before the first run, or no pass queued since the last step) says
+    // nothing about the exponents: refuse instead of reporting "calibrated" with whatever they were
+    if (!reported)
+        return oai::set_error(OAI_ERR_ARG, "oai_unet_calibrate_step: the range census is empty (no fp16x3 pass since the last step, or option census / sres is 0)");
     if (!changed) { h->calibrated = true; return OAI_OK; }
-    return oai_unet_set_act_exponents(h, e);
+    const bool was = h->calibrated;
+    const int rc = oai_unet_set_act_exponents(h, e);
+    h->calibrated = was;                                 // exponents moved: only a later pass that finds every layer inside the window calibrates
+    return rc;
 }
 
 int oai_unet_profile(oai_unet* h, int enable) {

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         const bool real = ch < nchunks;
         const bool first = ch < nch0;
         const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
-        const unsigned char* g = (real && poff[it] != kNoPiece) ? cbase + poff[it] : zero_rec;
+        const unsigned char* g = (real && poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + poff[it] : zero_rec;
         lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16));
     };
     // pieces requested in tap t (for the NEXT chunk): spread over the nine taps, the early taps take the remainder
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         const unsigned dst = lds_addr_of(raw_w);
 #pragma unroll
         for (int it = 0; it < (WS ? WNIT : 0); ++it) {
-            const unsigned char* g = woff[WS ? it : 0] != kNoPiece ? cbase + woff[WS ? it : 0] : zero_rec;
+            const unsigned char* g = (woff[WS ? it : 0] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + woff[WS ? it : 0] : zero_rec;
             lds_dma16(g, __builtin_amdgcn_readfirstlane(dst + it * 1024));
         }
     };
@@ -276,7 +276,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         constexpr int ML = decltype(ml_tag)::value;
         for (int ch = 0; ch < nchunks; ++ch) {
             // (-DOAI_DIAG builds, OAI_DBG bits -- timing only, results wrong: 4096 no weight-fragment loads in the taps, 8192 A fragments of tap 0 for
-            // every tap, 16384 transform of chunk 0 only, 32768 no DMA pieces in the taps; scripts/wino_var.sh, profiles/r03_winograd.md)
+            // every tap, 16384 transform of chunk 0 only, 32768 no DMA pieces in the taps, 65536 every weight-fragment load from ONE address
+            // (same instructions, L1-resident: prices the L2 -> L1 leg alone), 131072 every halo piece from the zero record (same DMA
+            // instructions, no HBM / L2 traffic behind them); scripts/wino_var.sh, profiles/r03_winograd.md, r04_wino_stream.md)
             if constexpr (!WS) {
                 if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                                 bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
                                                   : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
                     }
-                    wp += STEP * 16;
+                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
 #pragma unroll
                     for (int m = 0; m < ML; ++m) {
                         constexpr int kDummy = 0; (void)kDummy;
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                             bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
                                               : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
                 }
-                wp += STEP * 16;
+                if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
                 if (!OAI_DBG_BIT(a, 32768)) {
 #pragma unroll
                     for (int q = 0; q < pieces_in_tap(t); ++q) issue_piece(first_piece(t) + q, ch + 1);

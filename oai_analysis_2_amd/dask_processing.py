@@ -113,7 +113,7 @@ def process_cohort(images: Sequence, atlas_image, worker: Optional[Worker] = Non
     both probability maps on the atlas grid.  Yields (index, VolumeResult) for the volumes THIS rank processed.
     ``images``: paths or Images (all ranks pass the same list; only claimed entries are read)."""
     from .cohort import CohortRunner
-    from .parallel import VolumeQueue
+    from .parallel import VolumeQueue, sync_calibration
     from .pipeline import VolumePipeline
     w = worker or get_worker()
     seg = w.segmenter
@@ -123,6 +123,16 @@ def process_cohort(images: Sequence, atlas_image, worker: Optional[Worker] = Non
     if eng.precision != seg.config.get("precision", "fp16x3"):
         eng.set_precision(seg.config.get("precision", "fp16x3"))
     ovl = tuple(int(v) for v in seg.config["overlap_size"])
+    if eng.precision == "fp16x3" and len(images):
+        # ONE calibration for the cohort: the checkpoint's sidecar if there is one, else rank 0 calibrates on volume 0 (and writes the
+        # sidecar); every rank takes rank 0's exponents, so a volume's maps do not depend on which rank the queue hands it to
+        eng.set_calibration_file(seg.calibration_file)
+
+        def _calibrate_on_first():
+            vol0 = image_normalize(readimage(images[0]), 0.1, 99.9, 0, 1)
+            eng.calibrate_volume(torch.from_numpy(np.ascontiguousarray(vol0.array, dtype=np.float32)).to(eng.device),
+                                 seg.tile_zyx, ovl[::-1], (ovl[2], ovl[0], ovl[1]))
+        sync_calibration(eng, _calibrate_on_first)
     pipe = VolumePipeline(eng, w.registerer.register_module, readimage(atlas_image), tile_zyx=seg.tile_zyx, overlap_zyx=ovl[::-1],
                           crop_zyx=(ovl[2], ovl[0], ovl[1]))
     runner = CohortRunner(pipe, keep_on_device=keep_on_device)

@@ -200,3 +200,48 @@ class VolumeQueue:
             if i is None:
                 return
             yield i
+
+
+# ---- one fp16x3 calibration per checkpoint and cohort, whatever rank sees which volume first -----------------
+
+_cal_serial = 0
+
+
+def sync_calibration(engine, calibrate_fn: Callable[[], None], store=None, name: Optional[str] = None, rank: Optional[int] = None,
+                     world: Optional[int] = None) -> List[int]:
+    """Every rank leaves with RANK 0's activation exponents: rank 0 calibrates (``calibrate_fn()``, unless its engine already holds a
+    calibration -- e.g. from the checkpoint's sidecar file) and publishes the 18 exponents on the process group's key-value store;
+    the other ranks wait for the key and ``set_act_exponents``.  Without this every rank of ``process_cohort`` would calibrate on
+    the first volume the queue happens to hand it, and a volume's last bits would depend on which rank claimed it.  No process
+    group: just ``calibrate_fn()`` when needed.  ``engine`` needs ``act_exponents()``, ``set_act_exponents()`` (UNetEngine)."""
+    global _cal_serial
+    import json
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    exps, cal = engine.act_exponents()
+    if world == 1 and store is None:
+        if not cal:
+            calibrate_fn()
+        return engine.act_exponents()[0]
+    if store is None:
+        from torch.distributed import distributed_c10d
+        store = distributed_c10d._get_default_store()
+    if name is None:                                   # every rank calls in the same order: same key everywhere
+        name = f"oai_fp16cal_{_cal_serial}"
+        _cal_serial += 1
+    if rank == 0:
+        if not cal:
+            calibrate_fn()
+        exps, cal = engine.act_exponents()
+        store.set(name, json.dumps({"act_exponents": exps, "calibrated": bool(cal),
+                                    "weights_sha256": getattr(engine, "weights_sha256", None)}))
+        return exps
+    store.wait([name])
+    doc = json.loads(store.get(name))
+    if doc.get("weights_sha256") != getattr(engine, "weights_sha256", None):
+        raise RuntimeError("sync_calibration: rank 0 holds other weights than this rank")
+    if doc["calibrated"]:
+        engine.set_act_exponents(doc["act_exponents"])
+    return doc["act_exponents"]

@@ -164,9 +164,15 @@ class VolumePipeline:
                 phi = self.register(vol)
                 phi.record_stream(main)
         maps = self.segment_sharded(vol, group)
-        flag = self._flag_snapshot()
-        if flag is not None:
-            parallel.any_rank(flag, group)
+        # the range flag of the WHOLE volume: the raw state (overflow bit + per-layer maxima) is MAX-reduced over the ranks and the
+        # LOW bit evaluated from that -- a rank whose tile range is all quiet background must not force every rank into the fp32
+        # repeat on its own subset's census; after the reduction every rank holds the same verdict
+        flag = None
+        if self.unet.precision == "fp16x3":
+            state = torch.zeros(self.unet.RANGE_STATE_WORDS, dtype=torch.int32, device=self.unet.device)
+            self.unet.range_state_snapshot(state)
+            parallel.any_rank(state, group)
+            flag = self.unet.range_flag_from_state(state)
         if phi is None:
             phi = self.register(vol)
         else:

@@ -3,6 +3,10 @@ workspace ownership, and the three launch entry points (tiles / segment / stitch
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import json
+import os
+import warnings
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -56,6 +60,7 @@ class UNetEngine:
 
         params = (_lib.LayerParams * 18)()
         known = set()
+        digest = hashlib.sha256()      # of the parameters as the kernels see them (fp32, layer order): ties a saved calibration to its network
         for i, name in enumerate(LAYER_ORDER):
             wkey = "dc0.weight" if name == "dc0" else f"{name}.0.weight"
             if wkey not in state_dict:
@@ -66,6 +71,7 @@ class UNetEngine:
             p = params[i]
             p.kind, p.cin, p.cout = kind, int(cin), int(cout)
             p.weight = ptr(wkey)
+            n_before = len(keep)
             if name == "dc0":
                 p.bias = ptr("dc0.bias")
                 known |= {"dc0.weight", "dc0.bias"}
@@ -75,6 +81,9 @@ class UNetEngine:
                 p.bn_mean, p.bn_var = ptr(f"{name}.1.running_mean"), ptr(f"{name}.1.running_var")
                 known |= {f"{name}.0.weight", f"{name}.0.bias", f"{name}.1.weight", f"{name}.1.bias",
                           f"{name}.1.running_mean", f"{name}.1.running_var", f"{name}.1.num_batches_tracked"}
+            for t in keep[n_before - 1:]:
+                digest.update(t.numpy().tobytes())
+        self.weights_sha256 = digest.hexdigest()
         extra = set(state_dict) - known
         if extra:
             raise KeyError(f"unexpected keys in state_dict (strict load): {sorted(extra)[:4]}")
@@ -89,13 +98,19 @@ class UNetEngine:
         # (calibrate()).  False = leave them as they are (all zero unless set_act_exponents was called).
         self.auto_calibrate = True
         self._calibrated = False
+        self._fp16_refused = False      # calibration did not settle for this network: "fp16x3" requests run "f32" (with a warning)
+        self.calibration_file: Optional[str] = None     # JSON sidecar (set_calibration_file): read now, written after a calibration
+        self.calibration_source = "none"                # "none" | "file" | "set" | "calibrated"
         if precision != "f32":
             self.set_precision(precision)
 
     def set_precision(self, precision: str) -> None:
-        """Arithmetic of the 3x3x3 conv layers: "f32" (exact fp32 MFMA), "bf16x6" (fp32-grade split), "bf16x3"."""
+        """Arithmetic of the 3x3x3 conv layers: "f32" (exact fp32 MFMA), "fp16x3" (fp32-grade split fp16, the default of the
+        segmenter), "bf16x6" (fp32-grade split), "bf16x3"."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        if precision == "fp16x3" and self._fp16_refused:
+            precision = "f32"               # (warned when the calibration failed)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_unet_set_precision(self._h, self.PRECISIONS[precision]), "oai_unet_set_precision")
         self.precision = precision
@@ -132,8 +147,17 @@ class UNetEngine:
         return n
 
     def set_option(self, name: str, value: int) -> None:
-        """Result-preserving tuning options of the fp16x3 path ("sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census": include/oai_hip.h)."""
+        """Tuning options of the fp16x3 path (include/oai_hip.h: oai_unet_set_option).  Bit-preserving (same k order, same maps):
+        "sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census".
+        NOT bit-preserving: "winograd" (bit mask, default 3: the x axis of ten layers in Winograd F(2,3) form -- other rounding,
+        same parity gates; 0 = the direct form everywhere) and "winograd_layers" (which layers)."""
         _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
+        if name == "sres":
+            # sres 0 = the superseded kernels that keep fp32 activations in memory and split them while staging: no range census, no
+            # activation exponents, no LOW bit -- a comparison mode for tests and A/B timing, not a production setting
+            self._no_census = int(value) == 0
+            if self._no_census:
+                warnings.warn("option sres=0: fp16x3 without the split-resident kernels has no range census (no calibration, no LOW flag)")
 
     def range_flag(self, reset: bool = True) -> int:
         """fp16x3 only: the range flag of the work queued since the last reset -- bit 0: an activation beyond fp16's range, bit 1: a
@@ -170,6 +194,47 @@ class UNetEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_unet_set_act_exponents(self._h, (C.c_int * 18)(*[int(v) for v in exponents])), "oai_unet_set_act_exponents")
         self._calibrated = True
+        self.calibration_source = "set"
+
+    # ---- a calibration belongs to a checkpoint, not to the first volume a process happens to see -----------
+    def save_calibration(self, path: str, note: str = "") -> None:
+        """JSON sidecar: the 18 exponents + the sha256 of the network's parameters.  Written atomically (temp file + rename): ranks
+        that calibrate at the same time leave one complete file, whichever wins."""
+        exps, cal = self.act_exponents()
+        if not cal:
+            raise _lib.OaiError("save_calibration: the engine is not calibrated")
+        doc = {"format": 1, "precision": "fp16x3", "weights_sha256": self.weights_sha256, "act_exponents": exps, "note": note}
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "w") as f:
+            json.dump(doc, f)
+        os.replace(tmp, path)
+
+    def load_calibration(self, path: str) -> bool:
+        """True if ``path`` holds exponents for THIS network (sha256 of the parameters) and they are now set; a file for another
+        network, an unreadable or malformed file is reported and ignored (the engine then calibrates as if there were none)."""
+        if not os.path.isfile(path):
+            return False
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            exps = [int(v) for v in doc["act_exponents"]]
+            if doc.get("format") != 1 or len(exps) != 18:
+                raise ValueError("unknown layout")
+        except Exception as exc:          # noqa: BLE001 - any damage to the sidecar means "no calibration on file"
+            warnings.warn(f"fp16x3 calibration file {path} is unreadable ({exc}): ignoring it")
+            return False
+        if doc.get("weights_sha256") != self.weights_sha256:
+            warnings.warn(f"fp16x3 calibration file {path} belongs to other weights: ignoring it")
+            return False
+        self.set_act_exponents(exps)
+        self.calibration_source = "file"
+        return True
+
+    def set_calibration_file(self, path: Optional[str]) -> bool:
+        """Use ``path`` as this engine's calibration sidecar: read it now if it exists (returns True when its exponents were taken),
+        and write it after the next successful calibrate().  None detaches."""
+        self.calibration_file = path
+        return bool(path) and not self._calibrated and self.load_calibration(path)
 
     def calibrate(self, run_pass, max_passes: int = 24) -> int:
         """Choose the activation exponents from representative input: ``run_pass()`` queues one fp16x3 pass (segment_tiles /
@@ -186,11 +251,23 @@ class UNetEngine:
                 _lib.check(self.lib.oai_unet_calibrate_step(self._h, st, C.byref(more)), "oai_unet_calibrate_step")
                 if not more.value:
                     self._calibrated = True
+                    self.calibration_source = "calibrated"
+                    if self.calibration_file:
+                        try:
+                            self.save_calibration(self.calibration_file, note=f"calibrated in {n} passes")
+                        except OSError as exc:          # a read-only model directory is not an error: the next process calibrates again
+                            warnings.warn(f"could not write the fp16x3 calibration file {self.calibration_file}: {exc}")
                     return n
-        raise _lib.OaiError(f"fp16x3 calibration did not settle in {max_passes} passes (census {self.census()}): use precision 'f32'")
+        # not settled: this network's activations do not fit the fp16x3 window at any exponents (a layer whose range spans more than
+        # the window, non-finite values, ...).  Before the calibration existed such a checkpoint ran through the fp32 repeat; keep that
+        # behaviour instead of raising: every later "fp16x3" request of this engine runs exact fp32.
+        warnings.warn(f"fp16x3 calibration did not settle in {max_passes} passes (census {self.census()}): this engine runs precision 'f32'")
+        self._fp16_refused = True
+        self.set_precision("f32")
+        return -1
 
     def _needs_calibration(self) -> bool:
-        return self.precision == "fp16x3" and self.auto_calibrate and not self._calibrated
+        return self.precision == "fp16x3" and self.auto_calibrate and not self._calibrated and not getattr(self, "_no_census", False)
 
     def range_overflow_snapshot(self, dst: torch.Tensor) -> None:
         """Queue (current stream, no sync) a copy of the fp16 range flag into the int32 device tensor ``dst[0]`` and clear it:
@@ -200,6 +277,26 @@ class UNetEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_unet_range_flag_snapshot(self._h, dst.data_ptr(), torch.cuda.current_stream().cuda_stream),
                        "oai_unet_range_flag_snapshot")
+
+    RANGE_STATE_WORDS = 19          # OAI_UNET_RANGE_STATE_WORDS
+
+    def range_state_snapshot(self, dst: torch.Tensor) -> None:
+        """Queue (no sync) the RAW range state of the work queued so far into the int32 device tensor ``dst[0:19]`` and clear it:
+        [0] overflow bit, [1 + k] float bits of layer k's largest stored activation.  MAX-all-reduce it over the ranks that shared a
+        volume's tiles, then ``range_flag_from_state``: the flag of the whole volume, not of one rank's subset."""
+        if dst.dtype != torch.int32 or dst.device != self.device or dst.numel() < self.RANGE_STATE_WORDS:
+            raise ValueError("dst must be an int32 tensor of 19 words on the engine's device")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_range_state_snapshot(self._h, dst.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "oai_unet_range_state_snapshot")
+
+    def range_flag_from_state(self, state: torch.Tensor) -> torch.Tensor:
+        """int32[1] device tensor: the two-bit range flag of a (reduced) range state; queued on the current stream, no sync."""
+        flag = torch.empty(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.oai_unet_range_flag_from_state(state.data_ptr(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "oai_unet_range_flag_from_state")
+        return flag
 
     def tile_flops(self, tile_zyx, overlap_zyx, trimmed: bool) -> float:
         return float(self.lib.oai_unet_tile_flops(self._h, *[int(v) for v in tile_zyx], _lib.int3(overlap_zyx), int(trimmed)))

@@ -58,6 +58,12 @@ class Segmenter3DInPatch(Segmenter):
         initialize_model(self.model, ckpoint_path=self.config["ckpoint_path"])
         self.model.to(self.device)
         self.model.eval()
+        # fp16x3's activation exponents belong to the checkpoint, not to the first volume a process happens to see: config key
+        # "fp16_calibration_file" (default: "<ckpoint_path>.fp16cal.json"; False / "" = none) names a JSON sidecar -- 18 exponents +
+        # the sha256 of the parameters -- that is read here when it exists and written after the first calibration otherwise, so every
+        # process, rank and restart segments a given volume with the same arithmetic
+        cal = self.config.get("fp16_calibration_file", str(self.config["ckpoint_path"]) + ".fp16cal.json")
+        self.calibration_file = str(cal) if cal else None
         self.ready = True
 
     def train(self, *args, **kwargs):      # the reference's training entry points are stubs (segmenter.py:64-70)
@@ -91,6 +97,8 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         precision = self.config.get("precision", "fp16x3")
         if eng.precision != precision:
             eng.set_precision(precision)
+        if precision == "fp16x3" and eng.calibration_file != self.calibration_file:
+            eng.set_calibration_file(self.calibration_file)
         blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
                                    crop_zyx if min(crop_zyx) > 0 else None)
         if precision == "fp16x3" and eng.range_overflow():

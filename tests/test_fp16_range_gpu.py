@@ -187,3 +187,93 @@ def test_an_overflowing_transformed_input_of_the_winograd_form_raises_the_flag()
         flags[wino] = eng.range_flag()
     assert flags[0] & bit == 0, "the direct form has nothing to report: every stored activation fits fp16"
     assert flags[3] & bit == bit, "an overflowing Winograd input must raise the overflow bit"
+
+
+# ---- the calibration belongs to the checkpoint (VERDICT r3 weak #8 / ADVICE r3 medium) ---------------------------------------------
+
+def _seg_config(td, **extra):
+    return dict(ckpoint_path=os.path.join(td, "segmentation_model.pth.tar"), training_config_file=os.path.join(td, "cfg.pth.tar"),
+                device="cuda", batch_size=4, overlap_size=(16, 16, 8), output_prob=True, output_itk=True, **extra)
+
+
+def _write_models(td, seed):
+    import json
+    with open(os.path.join(td, "cfg.pth.tar"), "w") as f:
+        json.dump({"patch_size": [128, 128, 32], "model": "UNet", "model_setting": {"in_channels": 1, "n_classes": 2, "bias": True, "BN": False}}, f)
+    torch.save({"model_state_dict": make_unet_state_dict(seed=seed), "epoch": 1}, os.path.join(td, "segmentation_model.pth.tar"))
+
+
+def test_calibration_is_persisted_next_to_the_checkpoint_and_shared_between_workers(tmp_path):
+    """Two workers (two processes in production: dask_processing.Worker per rank) that see DIFFERENT first volumes return
+    torch.equal maps for a common third volume, because the first one's calibration was written to the checkpoint's sidecar and
+    the second one read it; without the sidecar the two calibrations may differ and the difference is reported (last-ulp level)."""
+    import json
+    from oai_analysis_2_amd.segmentation.segmenter import Segmenter3DInPatchClassWise
+    td = str(tmp_path)
+    _write_models(td, 5)
+    shape = (40, 200, 200)
+    # volume a: the usual knee-like range; volume b: 6 x quieter, so a worker calibrating on it picks other exponents
+    va, vb, vc = make_volume(1, shape), make_volume(2, shape) * 0.15, make_volume(3, shape)
+    sidecar = os.path.join(td, "segmentation_model.pth.tar.fp16cal.json")
+    w1 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
+    w1.segment_array(va, True)
+    assert os.path.isfile(sidecar) and w1.model.engine.calibration_source == "calibrated"
+    doc = json.load(open(sidecar))
+    assert doc["weights_sha256"] == w1.model.engine.weights_sha256 and doc["act_exponents"] == w1.model.engine.act_exponents()[0]
+    w2 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
+    w2.segment_array(vb, True)                                   # its first volume: would calibrate differently on its own
+    assert w2.model.engine.calibration_source == "file" and w2.model.engine.act_exponents() == w1.model.engine.act_exponents()
+    m1, m2 = w1.segment_array(vc, True, as_device_tensor=True), w2.segment_array(vc, True, as_device_tensor=True)
+    assert torch.equal(m1, m2)
+    # without a sidecar: each worker calibrates on its own first volume
+    cfg = _seg_config(td, fp16_calibration_file=False)
+    w3, w4 = Segmenter3DInPatchClassWise(mode="pred", config=cfg), Segmenter3DInPatchClassWise(mode="pred", config=cfg)
+    w3.segment_array(va, True)
+    w4.segment_array(vb, True)
+    e3, e4 = w3.model.engine.act_exponents()[0], w4.model.engine.act_exponents()[0]
+    m3, m4 = w3.segment_array(vc, True, as_device_tensor=True), w4.segment_array(vc, True, as_device_tensor=True)
+    d = float((m3 - m4).abs().max())
+    print(f"[fp16 calibration] exponents from volume a {e3}\n[fp16 calibration] exponents from volume b {e4}\n"
+          f"[fp16 calibration] max|dp| on a common volume between the two calibrations, no sidecar: {d:.2e} "
+          f"(with the sidecar: 0, torch.equal)")
+    assert e3 != e4 and d < 1e-5 and torch.equal(m3, m1)          # (a's calibration is the sidecar's)
+    # a sidecar of another checkpoint is refused (sha256 of the parameters), a damaged one ignored: the worker calibrates itself
+    td2 = os.path.join(td, "other")
+    os.makedirs(td2)
+    _write_models(td2, 6)
+    import shutil
+    shutil.copy(sidecar, os.path.join(td2, "segmentation_model.pth.tar.fp16cal.json"))
+    w5 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td2))
+    with pytest.warns(UserWarning, match="other weights"):
+        w5.segment_array(va, True)
+    assert w5.model.engine.calibration_source == "calibrated"
+    assert json.load(open(os.path.join(td2, "segmentation_model.pth.tar.fp16cal.json")))["weights_sha256"] == w5.model.engine.weights_sha256
+
+
+def test_a_network_that_cannot_be_calibrated_runs_f32_with_a_warning():
+    """calibrate() used to raise when it did not settle; before calibration existed such a checkpoint simply ran through
+    the fp32 repeat.  Now: a warning, and every fp16x3 request of that engine runs exact fp32 (results = the f32 engine's)."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    sd = make_unet_state_dict(seed=0, width_div=4)
+    vol = torch.from_numpy(make_volume(4, (32, 64, 64))).cuda()
+    eng = UNetEngine(sd, precision="fp16x3")
+    orig = eng.calibrate
+    eng.calibrate = lambda run_pass, max_passes=24: orig(run_pass, max_passes=0)       # give up at once: no pass allowed
+    with pytest.warns(UserWarning, match="did not settle"):
+        blocks = eng.segment_tiles(vol, (32, 64, 64), (8, 16, 16), out_mode=2, batch=1)
+    assert eng.precision == "f32"
+    eng.set_precision("fp16x3")
+    assert eng.precision == "f32"                                  # sticky for this engine
+    ref = UNetEngine(sd, precision="f32").segment_tiles(vol, (32, 64, 64), (8, 16, 16), out_mode=2, batch=1)
+    assert torch.equal(blocks, ref)
+
+
+def test_calibrate_step_refuses_an_empty_census_and_census_off_needs_a_calibration():
+    from oai_analysis_2_amd import _lib
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    eng = UNetEngine(make_unet_state_dict(seed=0, width_div=4), precision="fp16x3")
+    with pytest.raises(_lib.OaiError, match="census 0 needs a calibrated handle"):
+        eng.set_option("census", 0)
+    with pytest.raises(_lib.OaiError, match="census is empty"):
+        eng.calibrate(lambda: None)                                # no pass was queued: nothing to calibrate from
+    assert eng.act_exponents() == ([0] * 18, False)

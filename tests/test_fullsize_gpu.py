@@ -31,6 +31,60 @@ def full(request):
     return dict(sd=sd, eng=eng, vol=vol, v=v, logits=logits, prob=prob, precision=request.param)
 
 
+def _reference_noise(golden_dir, case):
+    """(sum|p_ref32 - p_ref64| per class scaled to 23.6 M voxels, max|p_ref32 - p_ref64|, tiles, truth, ref32) of one case from
+    tests/golden/segment_fullsize_truth.npz: the REFERENCE's own network (networks.py:38-149) on six interior tiles in float32 -- bit-identical
+    to its full segment() run, asserted by the generator -- and in float64.  Its own fp32 rounding noise, in the unit of its acceptance
+    test, is what an absolute budget has to be read against: 2.1 / 1.4 on the base network, 6.5 / 9.1 on the BN network (logits +-5)."""
+    t = np.load(os.path.join(golden_dir, "segment_fullsize_truth.npz"))
+    truth, ref32 = t[f"{case}_truth"], t[f"{case}_ref32"].astype(np.float64)
+    return t[f"{case}_ref_err"], float(np.abs(ref32 - truth).max()), t[f"{case}_tiles"], truth, ref32
+
+
+def _compare_with_golden(z, vol, prob, mask, tag, golden_dir, case):
+    """prob [2,D,H,W] float32 numpy, mask [2,D,H,W] bool numpy against one segment_fullsize*.npz.
+
+    Budgets: the reference accepts sum|dp| < 12 per 23.6 M voxels against maps stored from another machine (test/test_all.py:32-33) --
+    an absolute number, set for the released network.  Here: max(12, 3 x the reference's OWN fp32-vs-fp64 distance on this network),
+    and pointwise max(1e-5, 8 x its largest fp32-vs-fp64 difference) -- on the base and the windowed case that IS 12 and 1e-5.
+    And directly against the float64 run of the reference's network on six tiles: the GPU path may be at most 3 x as far from the
+    truth as the reference's own fp32 run is."""
+    assert hashlib.sha256(vol.tobytes()).digest() == bytes(z["volume_sha256"]), "the GPU box regenerated a different input volume"
+    noise, noise_max, t_tiles, truth, ref32 = _reference_noise(golden_dir, case)
+    point_tol = max(1e-5, 8.0 * noise_max)
+    n = prob[0].size
+    sl = tuple(slice(int(a), None, int(st)) for a, st in zip(z["start"], z["stride"]))
+    sums = []
+    for c, key in enumerate(("fc_prob_s", "tc_prob_s")):
+        ref_s = z[key].astype(np.float64)
+        d = np.abs(prob[c][sl].astype(np.float64) - ref_s)
+        scaled = d.sum() * (n / ref_s.size)
+        sums.append(scaled)
+        budget = max(12.0, 3.0 * float(noise[c]))
+        print(f"[fullsize {tag}] class {c}: sum|dp| scaled to 23.6M voxels = {scaled:.3f} (budget {budget:.1f}; the reference's own fp32 noise "
+              f"{noise[c]:.2f}), max|dp| = {d.max():.2e} (tolerance {point_tol:.1e})")
+        assert scaled < budget and d.max() < point_tol
+        assert abs(prob[c].astype(np.float64).sum() - float(z["prob_sum"][c])) < budget       # all voxels, not only the sample
+    # against the reference network's float64 run on the six truth tiles (kept-centre voxels z = 1, y = 2, x = 3 mod 4)
+    got = np.stack([prob[:, 16 * (t // 16):16 * (t // 16) + 16, 96 * ((t // 4) % 4):96 * ((t // 4) % 4) + 96, 96 * (t % 4):96 * (t % 4) + 96][:, 1::4, 2::4, 3::4]
+                    for t in t_tiles.tolist()]).astype(np.float64)
+    e_gpu = np.abs(got - truth).sum(axis=(0, 2, 3, 4))
+    e_ref = np.abs(ref32 - truth).sum(axis=(0, 2, 3, 4))
+    print(f"[fullsize {tag}] distance from the reference network's float64 run on 6 tiles, GPU / reference-fp32: "
+          f"{e_gpu[0] / e_ref[0]:.2f} (FC)  {e_gpu[1] / e_ref[1]:.2f} (TC)")
+    assert (e_gpu <= 3.0 * e_ref).all()
+    ref_mask = np.stack([np.unpackbits(z["fc_mask_bits"])[:n], np.unpackbits(z["tc_mask_bits"])[:n]]).astype(bool).reshape(2, *SHAPE)
+    flips = np.flatnonzero((mask != ref_mask).ravel())
+    near = dict(zip(z["near_idx"].tolist(), z["near_prob"].tolist()))
+    dist_ = [abs(near.get(int(i), 0.0) - 0.5) for i in flips]           # a flip outside the near-0.5 list counts as distance 0.5
+    print(f"[fullsize {tag}] mask flips vs the reference: {len(flips)} of {2 * n} voxels "
+          f"({int(ref_mask[0].sum())} FC / {int(ref_mask[1].sum())} TC voxels set; {len(near)} voxels within 1e-4 of 0.5); "
+          f"max |p_ref - 0.5| at a flip = {max(dist_, default=0.0):.2e}")
+    assert all(d < point_tol for d in dist_)
+    assert len(flips) <= 64
+    return len(flips), sums
+
+
 def test_full_volume_matches_reference_golden(full, golden_dir):
     """The reference's Segmenter3DInPatchClassWise.segment (segmenter.py:100-131) on the same seeded 384x384x160 volume:
     (iii) sum|dp| within the reference's own budget (test_all.py:32-33: < 12 per 23.6 M voxels), on a 1/64 strided sample scaled up;
@@ -38,28 +92,40 @@ def test_full_volume_matches_reference_golden(full, golden_dir):
     0.5 (summation order differs between any two conv implementations).  Flip counts are printed (pytest -s / GPUTEST log)."""
     z = np.load(os.path.join(golden_dir, "segment_fullsize.npz"))
     assert int(z["volume_seed"]) == 42 and int(z["weight_seed"]) == 0
-    assert hashlib.sha256(full["vol"].tobytes()).digest() == bytes(z["volume_sha256"]), "the GPU box regenerated a different input volume"
     eng, v = full["eng"], full["v"]
-    prob = full["prob"].cpu().numpy()
-    n = prob[0].size
-    sl = tuple(slice(int(a), None, int(st)) for a, st in zip(z["start"], z["stride"]))
-    for c, key in enumerate(("fc_prob_s", "tc_prob_s")):
-        ref_s = z[key].astype(np.float64)
-        d = np.abs(prob[c][sl].astype(np.float64) - ref_s)
-        scaled = d.sum() * (n / ref_s.size)
-        print(f"[fullsize {full['precision']}] class {c}: sum|dp| scaled to 23.6M voxels = {scaled:.3f} (budget 12), max|dp| = {d.max():.2e}")
-        assert scaled < 12.0 and d.max() < 1e-5
-        assert abs(prob[c].astype(np.float64).sum() - float(z["prob_sum"][c])) < 12.0          # all voxels, not only the sample
     mask = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=1, crop_zyx=CROP), SHAPE, TILE, OVL, CROP).cpu().numpy() > 0.5
-    ref_mask = np.stack([np.unpackbits(z["fc_mask_bits"])[:n], np.unpackbits(z["tc_mask_bits"])[:n]]).astype(bool).reshape(2, *SHAPE)
-    flips = np.flatnonzero((mask != ref_mask).ravel())
-    near = dict(zip(z["near_idx"].tolist(), z["near_prob"].tolist()))
-    dist_ = [abs(near.get(int(i), 0.0) - 0.5) for i in flips]           # a flip outside the near-0.5 list counts as distance 0.5
-    print(f"[fullsize {full['precision']}] mask flips vs the reference: {len(flips)} of {2 * n} voxels "
-          f"({int(ref_mask[0].sum())} FC / {int(ref_mask[1].sum())} TC voxels set; {len(near)} voxels within 1e-4 of 0.5); "
-          f"max |p_ref - 0.5| at a flip = {max(dist_, default=0.0):.2e}")
-    assert all(d < 1e-5 for d in dist_)
-    assert len(flips) <= 64
+    _compare_with_golden(z, full["vol"], full["prob"].cpu().numpy(), mask, full["precision"], golden_dir, "base")
+
+
+@pytest.mark.parametrize("precision", ["f32", "fp16x3"])
+@pytest.mark.parametrize("case", ["bn", "dc", "win"])
+def test_full_volume_matches_reference_golden_on_other_networks_and_inputs(case, precision, golden_dir):
+    """the gates of the base case under the headline arithmetic (fp16x3 + Winograd) on three more reference runs, each ~9
+    CPU-minutes of the reference's own segment() (tests/golden/make_golden_fullsize.py --case ...); budgets read against the
+    reference's own fp32 noise on each network (_compare_with_golden; measured: the fp16x3 path sits 1.5-1.7 x that noise away from
+    the reference in every case, the exact-fp32-product kernel 2.3-2.7 x):
+    bn  -- weight seed 1 with BN=True (networks.py:39), volume seed 43;
+    dc  -- weight seed 2 with every conv bias + 1.0: DC-heavy activations, the regime where the Winograd input transform's
+           d1 + d2 / d0 - d2 terms cancel; volume seed 44;
+    win -- weight seed 3 on an intensity-windowed volume with 5 % of the voxels at exactly 0 and at exactly 1
+           (dask_processing.py:10-26), volume seed 45."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    from oai_analysis_2_amd.synth import FULLSIZE_CASES, make_fullsize_case
+    path = os.path.join(golden_dir, FULLSIZE_CASES[case]["file"])
+    if not os.path.isfile(path):
+        pytest.fail(f"{path} is missing: python tests/golden/make_golden_fullsize.py --case {case}")
+    z = np.load(path)
+    sd, vol, c = make_fullsize_case(case, SHAPE)
+    assert int(z["volume_seed"]) == c["volume_seed"] and int(z["weight_seed"]) == c["weight_seed"] and str(z["case"]) == case
+    eng = UNetEngine(sd, precision=precision)
+    v = torch.from_numpy(vol).cuda()
+    prob = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=0, crop_zyx=CROP), SHAPE, TILE, OVL, CROP)
+    mask = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=1, crop_zyx=CROP), SHAPE, TILE, OVL, CROP)
+    assert not eng.range_overflow()
+    assert torch.equal(mask, (prob > 0.5).float())
+    if precision == "fp16x3":
+        print(f"[fullsize {case}] activation exponents {eng.act_exponents()[0]}")
+    _compare_with_golden(z, vol, prob.cpu().numpy(), mask.cpu().numpy() > 0.5, f"{case} {precision}", golden_dir, case)
 
 
 def test_full_volume_properties(full):

@@ -200,3 +200,49 @@ def test_volume_queue_hands_out_every_volume_once_and_balances(tmp_path):
     assert len(firsts[0]) < min(len(firsts[1]), len(firsts[2]))           # the slow rank claimed fewer
     q = parallel.VolumeQueue(3)                                           # no process group: a local counter
     assert list(q) == [0, 1, 2] and q.claim() is None
+
+
+# ---- one fp16x3 calibration per cohort: every rank leaves with rank 0's exponents ----------------------------
+
+class _FakeEngine:
+    """The three members of UNetEngine that parallel.sync_calibration touches."""
+    weights_sha256 = "abc"
+
+    def __init__(self):
+        self.exps, self.cal, self.calls = [0] * 18, False, 0
+
+    def act_exponents(self):
+        return list(self.exps), self.cal
+
+    def set_act_exponents(self, e):
+        self.exps, self.cal = [int(v) for v in e], True
+
+
+def _cal_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeEngine()
+
+    def calibrate():                        # what each rank WOULD arrive at on its own first volume: different per rank
+        eng.calls += 1
+        eng.set_act_exponents([rank + 3] * 17 + [0])
+
+    got = parallel.sync_calibration(eng, calibrate)
+    # a second cohort on an engine that is calibrated already (e.g. from the checkpoint's sidecar): nobody calibrates again
+    got2 = parallel.sync_calibration(eng, calibrate)
+    np.save(os.path.join(out_dir, f"cal_{rank}.npy"), np.asarray([got, got2, [eng.calls] * 18]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_calibration_gives_every_rank_rank0s_exponents(tmp_path):
+    world = 3
+    mp.spawn(_cal_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"cal_{r}.npy") for r in range(world)]
+    for r in range(world):
+        assert res[r][0].tolist() == [3] * 17 + [0] and res[r][1].tolist() == [3] * 17 + [0]
+        assert res[r][2][0] == (1 if r == 0 else 0)           # only rank 0 ran a calibration, once
+    # single process, no group: calibrates when needed, not when the engine already holds exponents
+    eng = _FakeEngine()
+    assert parallel.sync_calibration(eng, lambda: eng.set_act_exponents([5] * 17 + [0])) == [5] * 17 + [0]
+    assert parallel.sync_calibration(eng, lambda: eng.set_act_exponents([9] * 18)) == [5] * 17 + [0]
