@@ -35,6 +35,8 @@ struct Layer {
     size_t panel_f16_floats = 0;
     float4* panel_wino = nullptr;       // fp16 panel of conv3_wino_sres (pack_wino_panel): the x axis in Winograd F(2,3) form; packed with the same ws / rel1
     size_t panel_wino_floats = 0;
+    float4* panel_wino16 = nullptr;     // the same weights laid out for the 16x16x32 taps of conv3_wino_sres<..., M16> (pack_wino16_panel; Cout % 128 == 0 only)
+    size_t panel_wino16_floats = 0;
     std::vector<float> wk_host;         // canonical [27][cin][cout] weights of the k3 layers (for re-packing)
     std::vector<float> scale_host, shift_host, plain_host;
     float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
@@ -59,7 +61,8 @@ struct oai_unet {
     bool calibrated = false;
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
-    int opt_wino = 3;                   // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs)
+    int opt_wino = 19;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
+                                        // bit 4 (round 4): the two-group form's taps on v_mfma_f32_16x16x32_f16 (same cycles per FLOP, +13 % clock at the power wall)
     int opt_wino_layers = 0x3FFFF;      // option "winograd_layers": bit k = layer k may take the Winograd kernel (A/B of single layers)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
@@ -256,6 +259,48 @@ static std::vector<float> pack_wino_panel(const std::vector<float>& wk, int C0, 
     return out;
 }
 
+// Panel of conv3_wino_sres<.., M16> (v_mfma_f32_16x16x32_f16, K = a PAIR of taps x 16 channels): [cb][frequency f][chunk of 16][step 5][X' | Y'][n2 4][lane]
+// x 8 fp16.  Lane (column c = lane & 15, group g = lane >> 4) of tile n2 holds cout cb * 64 + n2 * 16 + c, channels 8 (g & 1) .. + 7 of tap
+// 2 j + (g >> 1) (steps j < 4): X' = the HIGH terms b0 of both taps, Y' = the LOW terms b1.  Step 4 (the ninth tap alone, A = [a0 | a1]):
+// X' = [b0(8) | b0(8)], Y' = [b1(8) | 0].  The values are pack_wino_panel's (same transformed weights, same scales, same split).
+static std::vector<float> pack_wino16_panel(const std::vector<float>& wk, int C0, int C1, int Cout, const std::vector<float>& wscale, float src1_factor) {
+    const int Cin = C0 + C1, KC = 16;
+    const int ncb = Cout / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+    const size_t units = ((size_t)ncb * 4 * (nch0 + nch1) * 5 + 2) * 2 * 4 * 64;       // 16-byte units, + 2 steps of prefetch slack
+    std::vector<float> out(units * 4, 0.0f);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+    size_t u = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int f = 0; f < 4; ++f)
+            for (int ch = 0; ch < nch0 + nch1; ++ch) {
+                const bool first = ch < nch0;
+                const int Csrc = first ? C0 : C1, cofs = first ? 0 : C0, cl0 = (first ? ch : ch - nch0) * KC;
+                for (int j = 0; j < 5; ++j)
+                    for (int kind = 0; kind < 2; ++kind)             // 0: X', 1: Y'
+                        for (int n2 = 0; n2 < 4; ++n2)
+                            for (int lane = 0; lane < 64; ++lane, ++u) {
+                                const int g = lane >> 4, tsel = g >> 1;
+                                int t, term;
+                                if (j < 4) { t = 2 * j + tsel; term = kind; }
+                                else { t = 8; term = kind; if (kind == 1 && tsel == 1) continue; }     // step 4: X' = [b0 | b0], Y' = [b1 | 0]
+                                const int co = cb * 64 + n2 * 16 + (lane & 15);
+                                for (int e = 0; e < 8; ++e) {
+                                    const int cl = cl0 + 8 * (g & 1) + e;
+                                    if (cl >= Csrc) continue;
+                                    double gx[3];
+                                    for (int dx = 0; dx < 3; ++dx)
+                                        gx[dx] = (double)wk[((size_t)(t * 3 + dx) * Cin + cofs + cl) * Cout + co] * (double)wscale[co] * (first ? 1.0 : (double)src1_factor);
+                                    const double uf = f == 0 ? gx[0] : f == 1 ? 0.5 * (gx[0] + gx[1] + gx[2]) : f == 2 ? 0.5 * (gx[0] - gx[1] + gx[2]) : gx[2];
+                                    float r = (float)uf;
+                                    uint16_t b = 0;
+                                    for (int kk = 0; kk <= term; ++kk) { b = f32_to_f16_rne(r); r -= f16_to_f32(b); }
+                                    o16[u * 8 + e] = b;
+                                }
+                            }
+            }
+    return out;
+}
+
 // [N/64][Cin/8][2][lane] x float4 for upconv2_igemm_f32; column n = parity*Cout + co
 static std::vector<float> pack_up_panel(const oai_layer_params& p) {
     const int N = 8 * p.cout, nnb = (N + 63) / 64, nkg = (p.cin + 7) / 8;
@@ -333,7 +378,12 @@ static int pack_wino_layer(oai_unet* h, int k) {
     const std::vector<float> panel = pack_wino_panel(L.wk_host, L.c0, L.c1, L.cout, L.ws, ldexpf(1.0f, L.rel1));
     if (L.panel_wino && panel.size() != L.panel_wino_floats) return set_error(OAI_ERR_ARG, "Winograd panel of layer %d changed size", k);
     L.panel_wino_floats = panel.size();
-    return upload_into(h, panel, &L.panel_wino);
+    if (int rc = upload_into(h, panel, &L.panel_wino)) return rc;
+    if (L.cout % 128 != 0) return OAI_OK;                             // the 16x16x32 taps exist for the two-group form
+    const std::vector<float> p16 = pack_wino16_panel(L.wk_host, L.c0, L.c1, L.cout, L.ws, ldexpf(1.0f, L.rel1));
+    if (L.panel_wino16 && p16.size() != L.panel_wino16_floats) return set_error(OAI_ERR_ARG, "16x16x32 Winograd panel of layer %d changed size", k);
+    L.panel_wino16_floats = p16.size();
+    return upload_into(h, p16, &L.panel_wino16);
 }
 
 // The fp16 panel of layer k (k3 conv or k2s2 up-conv) for the current activation exponents.  Every output channel's weights are scaled
@@ -633,7 +683,10 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-    if (ng == 2) conv3_wino_sres<2, TY, NP><<<grid, 512, 0, st>>>(a, h->zero_rec);
+    if (ng == 2 && (h->opt_wino & 16) && L.panel_wino16) {              // the taps on v_mfma_f32_16x16x32_f16 (higher clock at the power wall)
+        a.wpanel = L.panel_wino16;
+        conv3_wino_sres<2, TY, NP, 1, false, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
+    } else if (ng == 2) conv3_wino_sres<2, TY, NP><<<grid, 512, 0, st>>>(a, h->zero_rec);
     else if constexpr (TY != 4) {
         // the specialised form takes ALL of a CU's LDS (160 KB): asked once whether a workgroup of it fits this device / driver at all
         static const bool ws_fits = [] {
@@ -1139,8 +1192,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         OAI_CHECK_ARG(value >= 0 && value <= 2, "oai_unet_set_option: wide must be 0, 1 or 2 (2 = also for launches of fewer than 1024 workgroups)");
         h->opt_wide = value;
     } else if (!strcmp(name, "winograd")) {            // bit 0: layers with Cout % 128 == 0 (two cout groups per workgroup), bit 1: one block of 64 couts and >= 8 chunks
-                                                       // (specialised waves); A/B only: bit 2 = the slice-split form instead, bit 3 = the specialised form for every layer
-        OAI_CHECK_ARG(value >= 0 && value <= 15, "oai_unet_set_option: winograd must be in [0, 15]");
+                                                       // (specialised waves); A/B only: bit 2 = the slice-split form instead, bit 3 = the specialised form for every layer;
+                                                       // bit 4: the two-group form's taps on v_mfma_f32_16x16x32_f16 (tap pairs; another summation order)
+        OAI_CHECK_ARG(value >= 0 && value <= 31, "oai_unet_set_option: winograd must be in [0, 31]");
         if (value && !h->opt_wino && h->L[EC0].scale_f16) {
             OAI_CHECK_HIP(hipDeviceSynchronize());
             for (int k = 1; k < 17; ++k)

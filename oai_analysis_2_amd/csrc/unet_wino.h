@@ -51,10 +51,23 @@ namespace oai {
 // chunk's pieces into the same places (no wave ever reads what another wave's DMA writes: no barrier inside the staging).  One barrier per
 // chunk; no transform phase and no halo piece in front of a weight fragment on the multipliers' path.  2 x 60 KB of T + 40 KB of raw rows =
 // the CU's 160 KB exactly.  (MS = 2 measured 0.43 MFMA-busy on dc2: its vector-memory path carries every weight fragment twice.)
-template <int NG, int TY, int NP, int MS = 1, bool WS = false>
+// M16 (round 4; NG = 2, MS = 1, not WS): the same block, staging, transform and epilogue with the taps on v_mfma_f32_16x16x32_f16 instead of
+// 32x32x16.  Why: this loop runs at the power wall, and at equal cycles per FLOP the 16x16x32 shape holds a ~12 % higher clock on split-fp16
+// data with the structure of this tap loop (scripts/micro/mfma_shape.hip, profiles/r04_wino_stream.md: 1.66 -> 1.86 GHz, 1309 -> 1465 TFLOP/s
+// executed at the same MFMA-busy share).  K = 32 is a PAIR OF TAPS x 16 channels, so every operand is a natural record read / panel load:
+//     step j < 4:  taps (2j, 2j+1);  lanes 0-31 carry tap 2j, lanes 32-63 tap 2j+1 (lane group g = lane >> 4: channel half g & 1, tap g >> 1)
+//         pass A  [a0(t) | a0(t')] . X'   X' = [b0(t) | b0(t')]        pass B  [a0 | a0'] . Y'   Y' = [b1(t) | b1(t')]        pass C  [a1 | a1'] . X'
+//     step 4:      the ninth tap alone -- lanes 32-63 carry its LOW terms:  pass A  [a0 | a1] . [b0 | b0] = a0.b0 + a1.b0;  pass B  [a0 | a1] . [b1 | 0]
+// = 14 K-32 MFMA steps per chunk where 13.5 would be exact (+3.7 %).  A wave's tile is the same 128 rows x 64 couts as 8 x 4 tiles of 16 x 16
+// (m2 = 2 m + p: rows 16 p .. 16 p + 15 of slice m; n2 = 2 n + q): the same 128 accumulator registers, element (p, q, i) of the old (m, n)
+// tile at row 16 p + 4 (lane >> 4) + i, cout column 16 q + (lane & 15).  Weight fragments: pack_wino16_panel, 40 KiB per chunk and 64 couts
+// (36 in the 32x32 form), X' double-buffered, Y' reloaded behind pass B: 48 registers.  Every accumulator sees a0.b0 (two taps at once),
+// a0.b1, a1.b0 per step: another summation order than the 32x32 form's, same arithmetic class (tests: the Winograd gates).
+template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false>
 __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
+    static_assert(!M16 || (MS == 1 && !WS), "the 16x16x32 taps exist for the plain four-slice form");
     static_assert(!WS || (NG == 1 && MS == 1), "specialised waves: four multiply, four stage");
     constexpr int TZ = 4, TX = 2 * NP, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int RS = 4 * HX + 1;                                // 16-byte pieces per raw row (hz, hy): [term][hx][half] + 1 pad
@@ -94,13 +107,25 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     const int yl = row / NP, pr = row % NP;                       // this lane's A row: y, x pair
     const int m_lo = max(0, blo[0] - oz0), m_hi = min(TZ, bhi[0] - oz0);
 
-    f32x16 acc[MREP][NREP];
+    f32x16 acc[M16 ? 1 : MREP][M16 ? 1 : NREP];
+    f32x4 acc4[M16 ? MREP : 1][M16 ? NREP : 1][4];                    // M16: [m][n][p * 2 + q], element i at row 16 p + 4 (lane >> 4) + i, column 16 q + (lane & 15)
 #pragma unroll
-    for (int m = 0; m < MREP; ++m)
+    for (int m = 0; m < (M16 ? 1 : MREP); ++m)
 #pragma unroll
-        for (int n = 0; n < NREP; ++n)
+        for (int n = 0; n < (M16 ? 1 : NREP); ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < (M16 ? MREP : 1); ++m)
+#pragma unroll
+        for (int n = 0; n < (M16 ? NREP : 1); ++n)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc4[m][n][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // element r (0..15) of the (m, n) tile, whichever shape holds it
+    auto acc_el = [&](int m, int n, int r) __attribute__((always_inline)) -> float {
+        if constexpr (M16) return acc4[m][n][r >> 2][r & 3];
+        else return acc[m][n][r];
+    };
 
     const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
     const size_t plane = (size_t)a.D * a.H * a.W;
@@ -130,6 +155,30 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
         const unsigned char* g = (real && poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + poff[it] : zero_rec;
         lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16));
+    };
+    // M16: the piece from a wave-uniform base (SGPR pair) + a 32-bit per-lane offset -- no 64-bit per-lane address, no select against the zero
+    // record (hoisted out of the chunk loop those are ten more registers; spilled, their reload inside the taps drains vmcnt).  A piece outside
+    // the tile reads offset 0 of the plane (valid memory, unused data) and its LDS slot is zeroed behind the chunk-end wait (zero_missing);
+    // past the last chunk the last chunk is fetched again.
+    auto issue_piece_s = [&](int it, int ch) __attribute__((always_inline)) {
+        const int che = ch < nchunks ? ch : nchunks - 1;
+        const bool first = che < nch0;
+        const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? che : che - nch0) * plane * 64;     // wave-uniform chunk plane
+        const unsigned off = poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072) ? poff[it] : 0u;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(cbase), "s"(__builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16)) : "memory");
+    };
+    unsigned miss = 0;                                              // bit it: piece it of this thread lies outside the tile
+    if constexpr (M16) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) miss |= poff[it] == kNoPiece ? 1u << it : 0u;
+    }
+    auto zero_missing = [&]() __attribute__((always_inline)) {
+        if (__builtin_amdgcn_ballot_w64(miss != 0) == 0) return;     // (interior blocks: no wave has one)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (miss & (1u << it)) *reinterpret_cast<float4*>(raw + (it * NT + tid) * 16) = float4{0.0f, 0.0f, 0.0f, 0.0f};
     };
     // pieces requested in tap t (for the NEXT chunk): spread over the nine taps, the early taps take the remainder
     auto pieces_in_tap = [](int t) constexpr { return WS ? 0 : NIT / 9 + (t < NIT % 9 ? 1 : 0); };
@@ -173,9 +222,11 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         }
     };
     auto transform = [&]() __attribute__((always_inline)) {
+        int tq = tid;
+        if constexpr (M16) asm volatile("" : "+v"(tq));             // M16: the unit's addresses are recomputed every chunk instead of living in (spilled) registers through the taps
 #pragma unroll
         for (int ui = 0; ui < (UNITS + NT - 1) / NT; ++ui) {
-            const int u = ui * NT + tid;
+            const int u = ui * NT + tq;
             if (u < UNITS) {
                 const int p = u % NP;
                 int t = u / NP;
@@ -233,9 +284,35 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
 #pragma unroll
         for (int t = 0; t < 2; ++t) sl[dy][t] = ((t * 2 + half) ^ (((row + dy * NP) >> 2) & 3)) * 16;
 
-    constexpr int STEP = 2 * NREP * 64;                             // 16-byte units of weights per tap: [term][nr][lane]
-    // panel of pack_wino_panel: [cb][f][chunk][tap 9][term][nr][lane]; wave-uniform base, forced into an SGPR pair
-    const size_t wp_v = (size_t)(a.wpanel + (size_t)(cb * 4 + f) * nchunks * 9 * STEP);
+    // M16: byte offset (inside T) of this lane's record slot per step and term -- lane group g = lane >> 4 reads channel half g & 1 of tap
+    // 2 j + (g >> 1) (steps 0..3; term k), or of term g >> 1 of tap 8 (step 4); row r16 = lane & 15 of the 16-row tile p = 0 (p = 1: + 1024)
+    // (computed at the top of every chunk's taps from an opaque copy of the lane id: kept live through the transform -- the register peak of
+    // the chunk loop -- they are what tips the allocator into spilling)
+    unsigned a16[M16 ? 9 : 1];
+    auto compute_a16 = [&]() __attribute__((always_inline)) {
+        int lq = lane;
+        asm volatile("" : "+v"(lq));
+        const int r16 = lq & 15, hsel = (lq >> 4) & 1, tsel = lq >> 5;
+        const int y16 = r16 / NP, p16 = r16 % NP;
+        const unsigned rowofs = (unsigned)(((f * HY + y16) * NP + p16) * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = 2 * j + tsel, dz = t / 3, dy = t - 3 * dz;
+                const int key = ((r16 + dy * NP) >> 2) & 3;
+                a16[j * 2 + k] = rowofs + (unsigned)(((dz * 4 * HY + dy) * NP) * 64 + ((k * 2 + hsel) ^ key) * 16);
+            }
+        {
+            const int key = ((r16 + 2 * NP) >> 2) & 3;                // tap 8 = (dz 2, dy 2)
+            a16[8] = rowofs + (unsigned)(((2 * 4 * HY + 2) * NP) * 64 + ((tsel * 2 + hsel) ^ key) * 16);
+        }
+    };
+    constexpr int STEP = M16 ? 2 * 4 * 64 : 2 * NREP * 64;          // 16-byte units of weights per tap (M16: per STEP of two taps: [X' | Y'][n2 4][lane])
+    constexpr int NSTEPS = M16 ? 5 : 9;                             // fragment sets per chunk
+    // panel of pack_wino_panel: [cb][f][chunk][tap 9][term][nr][lane] (M16, pack_wino16_panel: [cb][f][chunk][step 5][X' | Y'][n2][lane]);
+    // wave-uniform base, forced into an SGPR pair
+    const size_t wp_v = (size_t)(a.wpanel + (size_t)(cb * 4 + f) * nchunks * NSTEPS * STEP);
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(
         ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wp_v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp_v));
     const unsigned wlane = lane * 16;
@@ -243,14 +320,25 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     // ---- prologue: the first raw box and the weight fragments of tap 0 (WS: the stagers also transform chunk 0 and request chunk 1)
     if constexpr (!WS) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) issue_piece(it, 0);
+        for (int it = 0; it < NIT; ++it) { if constexpr (M16) issue_piece_s(it, 0); else issue_piece(it, 0); }
     }
     // D = taps between the request of a fragment set and its use.  WS: a multiplier has its SIMD to itself -- nobody covers a wait -- and a tap
     // is 24 MFMAs = 0.37 us, less than an L2 round trip: D = 2, three register sets (9 % 3 == 0: the set of a tap does not depend on the chunk);
     // the registers come from the A fragments, see the slice-major tap below
     constexpr int D = WS ? 2 : 1, NB = D + 1;
     f32x4 bq[NB][2][NREP];                                          // [tap % NB][term][n]
-    if (!stager) {
+    f32x4 bXlo[2], bXhi[2], bY[4];                                  // M16: X' (the high terms b0), couts n 0, 1 and n 2, 3, and Y' (the low terms b1) of the running step
+    if constexpr (M16) {
+        sgpr_settle(wp);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { bXlo[n] = n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane); bXhi[n] = n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane); }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
+        wp += STEP * 16;
+        vm_wait<0>(bXlo[0], bXlo[1], bXhi[0], bXhi[1]);
+        vm_wait<0>(bY[0], bY[1], bY[2], bY[3]);
+        zero_missing();                                             // (the first raw box has landed with them)
+    } else if (!stager) {
         sgpr_settle(wp);                                            // wp has just been made uniform by v_readfirstlane
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -281,11 +369,132 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             // instructions, no HBM / L2 traffic behind them); scripts/wino_var.sh, profiles/r03_winograd.md, r04_wino_stream.md)
             if constexpr (!WS) {
                 if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
+                if constexpr (M16) compute_a16();                    // behind the transform's register peak, in front of the barrier: under the wait for the slowest wave
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                        // T is complete; the raw box is free for the next chunk's pieces
                 asm volatile("" ::: "memory");
             }
             const unsigned char* abase = Tl + (WS ? (ch & 1) * TB : 0) + aofs;
+            if constexpr (M16) {
+                // Five steps, pass order B, A, C -- a0 . Y', a0 . X', a1 . X'.  Y' is dead after the first pass: its registers take Y' of the
+                // next step a whole step ahead.  X' is live through the last two passes; so that its successor has more than pass B to land
+                // in, passes A and C run the LOW couts (n 0, 1) over all slices and then the HIGH couts (n 2, 3): X' lo is dead after C lo and
+                // re-requested there, X' hi at the end of the step, each 48 MFMAs (the 32x32 form's lead) before its first use in A lo / A hi of
+                // the next step.  32 fragment registers.  Vector-memory order per step: Y'(j+1) | lo(j+1) | hi(j+1) | pieces(j); the counted
+                // waits leave exactly the younger requests in flight.
+                constexpr int SL = 4 * HY * NP * 64;                    // bytes between the T images of consecutive z slices
+                auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
+                    return *reinterpret_cast<const float4*>(Tl + off + m * SL + p * 1024);
+                };
+                auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+                };
+                auto np_of = [](int j) constexpr { int c = 0; for (int q = 0; q < NIT; ++q) c += (q % 5 == j) ? 1 : 0; return c; };
+                static_assert(NIT <= 10, "at most two pieces per step (the waits below name 1 or 2)");
+                float4 af[MREP][2];                                     // [m][p]: the A fragments of the running pass
+#pragma unroll
+                for (int m = 0; m < ML; ++m)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[0], m, p);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    constexpr int kDummy = 0; (void)kDummy;
+                    const int npp = np_of((j + 4) % 5);                 // pieces requested at the end of the previous step
+                    // Y'(j) has landed; younger: lo(j), hi(j), pieces(j - 1)
+                    if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<6>(bY[0], bY[1], bY[2], bY[3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // pass B: a0 . Y'  (step 4: [a0 | a1] . [b1 | 0])
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) mma(af[m][p], bY[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!OAI_DBG_BIT(a, 4096)) {                        // Y' of the next step (of the next chunk behind step 4)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
+                    }
+                    // lo(j) has landed; younger: hi(j), pieces(j - 1), Y'(j + 1)
+                    if (npp == 1) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    // pass A, low couts: a0 . X'[0, 1] over all slices
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
+                    __builtin_amdgcn_sched_barrier(0);                  // (the wait below must not rise above these MFMAs: they are its lead)
+                    // hi(j) has landed; younger: pieces(j - 1), Y'(j + 1)
+                    if (npp == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    // pass A, high couts; behind each slice the a1 fragments of pass C take its registers
+#pragma unroll
+                    for (int m = 0; m < ML; ++m) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j < 4) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j * 2 + 1], m, p);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (j < 4) {
+                        // pass C, low couts: a1 . X'[0, 1] over all slices
+#pragma unroll
+                        for (int m = 0; m < ML; ++m)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!OAI_DBG_BIT(a, 4096)) {                        // the low couts of the next step's X'
+                        bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 4) {
+                        // pass C, high couts; behind each slice the a0 fragments of the next step (same chunk) take its registers
+#pragma unroll
+                        for (int m = 0; m < ML; ++m) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j < 3 ? (j + 1) * 2 : 8], m, p);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (!OAI_DBG_BIT(a, 4096)) {                        // the high couts of the next step's X'
+                        bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane);
+                    }
+                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+                    if (!OAI_DBG_BIT(a, 32768)) {
+#pragma unroll
+                        for (int q = 0; q < NIT; ++q)
+                            if (q % 5 == j) issue_piece_s(q, ch + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // chunk end: everything has landed -- the next raw box for this thread (the barrier says so for everybody, and that everybody
+                // is done reading T) and the fragments of the next chunk's step 0
+                vm_wait<0>(bXlo[0], bXlo[1], bXhi[0], bXhi[1]);
+                vm_wait<0>(bY[0], bY[1], bY[2], bY[3]);
+                zero_missing();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if constexpr (M16) continue;
+            else {                                                   // (discarded for M16: its accumulators have another type)
             if constexpr (WS) {
                 // the multiplier's chunk: 9 taps, slice-major -- per z slice m: a0[m].b0, a0[m].b1, a1[m].b0 for both cout halves (six MFMAs; every
                 // accumulator still sees a0.b0, a0.b1, a1.b0 in this order), with the fragment pair of the NEXT slice requested in front of
@@ -396,6 +605,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            }
         }
     };
     const int mlb = m_lo == 0 ? m_hi : TZ;                          // live z slices of the block (workgroup-uniform) ...
@@ -437,13 +647,17 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     const int nco = (a.Cout + 15) / 16;
     float vmax = 0.0f;
     bool nonfinite = false;                                         // an output inside the box that is inf / NaN (an overflowed t): fmaxf would drop the NaN silently
-    float scv[NREP], shv[NREP];
+    // this lane's cout column: lane & 31 of the 32-cout half n -- M16: columns 16 q + (lane & 15), q = 0, 1 (element (p, q, i) = r of the tile)
+    const int col16 = lane & 15, rq16 = lane >> 4;
+    float scv[NREP][M16 ? 2 : 1], shv[NREP][M16 ? 2 : 1];
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-        const int co = cb * 64 + n * 32 + row;
-        scv[n] = co < a.Cout ? a.scale[co] : 0.0f; shv[n] = co < a.Cout ? a.shift[co] : 0.0f;
-    }
-    asm volatile("" : "+v"(scv[0]), "+v"(scv[1]), "+v"(shv[0]), "+v"(shv[1]));
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int q = 0; q < (M16 ? 2 : 1); ++q) {
+            const int co = cb * 64 + n * 32 + (M16 ? q * 16 + col16 : row);
+            scv[n][q] = co < a.Cout ? a.scale[co] : 0.0f; shv[n][q] = co < a.Cout ? a.shift[co] : 0.0f;
+            asm volatile("" : "+v"(scv[n][q]), "+v"(shv[n][q]));
+        }
     int clo[3], chi[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { clo[i] = blo[i]; chi[i] = bhi[i]; }
@@ -457,9 +671,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         constexpr int F = decltype(ftag)::value;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
-            const int co = cb * 64 + n * 32 + row;
-            const bool cvalid = co < nco * 16;
-            const float sc = scv[n], sh = shv[n];
             __syncthreads();                                          // T reads / the previous half's copy-out are done
             // send: slice m of frequency F to wave m
 #pragma unroll
@@ -469,7 +680,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 const int slot = F * 3 + (m > F ? m - 1 : m);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = {acc[m][n][4 * j], acc[m][n][4 * j + 1], acc[m][n][4 * j + 2], acc[m][n][4 * j + 3]};
+                    const f32x4 v = {acc_el(m, n, 4 * j), acc_el(m, n, 4 * j + 1), acc_el(m, n, 4 * j + 2), acc_el(m, n, 4 * j + 3)};
                     *reinterpret_cast<f32x4*>(xb + ((slot * 4 + j) * 64 + lane) * 16) = v;
                 }
             }
@@ -480,7 +691,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             for (int g = 0; g < 4; ++g) {
                 if (g == F) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) M[g][r] = acc[F][n][r];
+                    for (int r = 0; r < 16; ++r) M[g][r] = acc_el(F, n, r);
                 } else {
                     const int slot = g * 3 + (F > g ? F - 1 : F);
 #pragma unroll
@@ -491,14 +702,19 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 }
             }
             __syncthreads();                                          // everybody has its frequencies: the buffer becomes the output image
-            const bool odd = row & 1;
+            const int ccol = M16 ? col16 : row;                       // cout column inside its 16-column (M16) / 32-column tile
+            const bool odd = ccol & 1;
             const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-            unsigned char* lrow = xb + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
             const int oz = oz0 + F;
             const bool zok = oz >= blo[0] && oz < bhi[0];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;      // C/D row of register r
+                // C/D row and 16-cout record of element r: 32x32 -- register r of the tile; 16x16 -- element i = r & 3 of tile (p, q) = (r >> 3, (r >> 2) & 1)
+                const int rr = M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int qrec = M16 ? (r >> 2) & 1 : row >> 4;
+                const bool cvalid = cb * 64 + n * 32 + qrec * 16 + (ccol & 15) < nco * 16;
+                const float sc = scv[n][M16 ? (r >> 2) & 1 : 0], sh = shv[n][M16 ? (r >> 2) & 1 : 0];
+                unsigned char* lrow = xb + qrec * 64 + ((ccol & 15) >> 1) * 4;
                 const int ty = rr / NP, tx = 2 * (rr % NP);
                 const float y0 = (M[0][r] + M[1][r]) + M[2][r];
                 const float y1 = (M[1][r] - M[2][r]) - M[3][r];
@@ -612,7 +828,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         __syncthreads();                                              // both slice pairs have their frequencies: the buffers become the output image
         const int co = cb * 64 + N * 32 + row;
         const bool cvalid = co < nco * 16;
-        const float sc = scv[N], sh = shv[N];
+        const float sc = scv[N][0], sh = shv[N][0];
         const bool odd = row & 1;
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         unsigned char* lrow = lds + (N * 2 + (row >> 4)) * 64 + ((row & 15) >> 1) * 4;
