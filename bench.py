@@ -39,7 +39,7 @@ DTYPE_OF = {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 ter
             "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
             "fp16x3": "fp16x3 (every fp32 value held as 2 fp16 terms = 22 mantissa bits, 3 MFMA passes per product, fp32 accumulate; "
                       "fp32 in and out of every entry point; full-size parity vs the reference in `parity`)"}
-TRAFFIC_FILE = {"f32": "profiles/r03_pmc_traffic_f32.json", "fp16x3": "profiles/r03_pmc_traffic_sres.json"}
+TRAFFIC_FILE = {"f32": "profiles/r04_pmc_traffic_f32.json", "fp16x3": "profiles/r04_pmc_traffic_sres.json"}
 
 
 def physical_cores() -> int:
@@ -513,7 +513,7 @@ def main():
                     "executed_frac_of_sustained_issue_rate": None if prec == "f32" else ach_fa * PASSES[prec] / SUSTAINED_16BIT_MFMA_TFLOPS,
                     "executed_note": None if prec == "f32" else
                     "executed_frac counts 3 MFMA passes per ALGORITHMIC product; the k3 layers without a fused ec0 / head (ec3-ec7 dc8 dc7 dc5 dc4 dc2, 78 % of the "
-                    "3x3x3 algorithmic FLOP) run the x axis in Winograd F(2,3) form and execute 2/3 of that (unet_wino.h, profiles/r03_winograd.md): for them "
+                    "3x3x3 algorithmic FLOP) run the x axis in Winograd F(2,3) form and execute 2/3 of that (unet_wino.h, profiles/r03_winograd.md, r04_wino_stream.md): for them "
                     "it overstates the matrix pipe's load, `frac` (algorithmic FLOP / time / peak) is the contract figure",
                     "algorithmic_flops_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                     "clock_note": None if prec == "f32" else

@@ -877,14 +877,43 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
             vs.vol = se->vol; vs.D = se->D; vs.H = se->H; vs.W = se->W; vs.td = se->PD; vs.th = se->PH; vs.tw = se->PW;
             vs.ez = se->PD; vs.ey = se->PH; vs.ex = se->PW; vs.oz = se->overlap[0]; vs.oy = se->overlap[1]; vs.ox = se->overlap[2]; vs.gy = 1; vs.gx = 1;
             const int per_row = se->grid[1] * se->grid[2], P[3] = {se->PD, se->PH, se->PW};
-            Box bx;
-            bx.lo[0] = se->eff[0] * (src.tile_begin / per_row); bx.hi[0] = se->eff[0] * ((src.tile_begin + n - 1) / per_row) + src.td;
-            bx.lo[1] = 0; bx.hi[1] = P[1]; bx.lo[2] = 0; bx.hi[2] = P[2];
             Scatter sc;
             sc.boxes = tb(DC2); sc.ntiles = n; sc.tile0 = src.tile_begin;
             for (int i = 0; i < 3; ++i) { sc.g[i] = se->grid[i]; sc.e[i] = se->eff[i]; }
             sc.t[0] = src.td; sc.t[1] = src.th; sc.t[2] = src.tw;
-            RUN(launch_conv3(h, L[EC1], nullptr, nullptr, buf[B_SYN0], P, bx, 1, st, nullptr, se->SP0, nullptr, &vs, nullptr, &sc));
+            // One launch per z slab of `eff` slices, over the y / x BOUNDING BOX of the batch's tiles that touch the slab (a tile of z row i
+            // covers the slabs [i, i + td / eff)): a whole volume is one box per slab = the full y / x extent as before, but a rank's share of
+            // a tile-sharded volume (19-23 tiles = parts of two or three z rows) no longer pays for the full extent of every row it touches
+            // (round 4: profiles/r04_tileshard_projection.md).  Values do not depend on the box: the halo is read from the padded volume.
+            const int t_first = src.tile_begin, t_last = src.tile_begin + n - 1;
+            const int zspan = (src.td + se->eff[0] - 1) / se->eff[0];           // slabs per tile (2 for 32 / 16)
+            const int s_first = t_first / per_row, s_last = t_last / per_row + zspan - 1;
+            Box prev{}; bool have_prev = false;
+            for (int s = s_first; s <= s_last; ++s) {
+                int jlo = 1 << 30, jhi = -1, klo = 1 << 30, khi = -1;
+                for (int i = s - zspan + 1; i <= s; ++i) {                      // z rows whose tiles cover slab s
+                    if (i < 0 || i >= se->grid[0]) continue;
+                    const int a0 = std::max(t_first, i * per_row), a1 = std::min(t_last, (i + 1) * per_row - 1);
+                    if (a0 > a1) continue;
+                    const int j0 = (a0 - i * per_row) / se->grid[2], j1 = (a1 - i * per_row) / se->grid[2];
+                    jlo = std::min(jlo, j0); jhi = std::max(jhi, j1);
+                    if (j0 == j1) { klo = std::min(klo, (a0 - i * per_row) % se->grid[2]); khi = std::max(khi, (a1 - i * per_row) % se->grid[2]); }
+                    else { klo = 0; khi = se->grid[2] - 1; }
+                }
+                if (jhi < 0) continue;
+                Box bx;
+                bx.lo[0] = se->eff[0] * s; bx.hi[0] = std::min(P[0], se->eff[0] * (s + 1));
+                if (s == s_last) bx.hi[0] = std::min(P[0], se->eff[0] * (t_last / per_row) + src.td);       // (the last slab takes the remainder of the tile height)
+                bx.lo[1] = se->eff[1] * jlo; bx.hi[1] = std::min(P[1], se->eff[1] * jhi + src.th);
+                bx.lo[2] = se->eff[2] * klo; bx.hi[2] = std::min(P[2], se->eff[2] * khi + src.tw);
+                if (have_prev && prev.lo[1] == bx.lo[1] && prev.hi[1] == bx.hi[1] && prev.lo[2] == bx.lo[2] && prev.hi[2] == bx.hi[2] && prev.hi[0] == bx.lo[0]) {
+                    prev.hi[0] = bx.hi[0];                                      // same footprint as the slab below: one launch for both
+                    continue;
+                }
+                if (have_prev) RUN(launch_conv3(h, L[EC1], nullptr, nullptr, buf[B_SYN0], P, prev, 1, st, nullptr, se->SP0, nullptr, &vs, nullptr, &sc));
+                prev = bx; have_prev = true;
+            }
+            if (have_prev) RUN(launch_conv3(h, L[EC1], nullptr, nullptr, buf[B_SYN0], P, prev, 1, st, nullptr, se->SP0, nullptr, &vs, nullptr, &sc));
         }
         // ---- the interior of this batch's pooled tensors is a copy, their faces are computed
         const int nch1 = (L[EC1].cout + 15) / 16;
