@@ -99,9 +99,10 @@ def check_no_sgpr_hazard(lib: str) -> None:
     s[b:b+1]`), where the stale SGPR is a wild address (csrc/unet_sres2.h: sgpr_settle)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("sgpr_hazard_scan", os.path.join(os.path.dirname(HERE), "scripts", "sgpr_hazard_scan.py"))
-    if not os.path.exists(spec.origin) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
-        print("[oai build] WARNING: the SGPR-hazard guard did not run", file=sys.stderr)
-        return
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"      # (located like check_no_packed_fp32 does)
+    if not os.path.exists(spec.origin) or not os.path.exists(objdump):
+        os.remove(lib)
+        raise RuntimeError("the SGPR-hazard guard cannot run (scripts/sgpr_hazard_scan.py or llvm-objdump missing): refusing to ship an unchecked library")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     hits = mod.scan_library(lib)
@@ -119,8 +120,8 @@ def check_no_packed_fp32(lib: str) -> None:
     import tempfile
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
-        print("[oai build] WARNING: no llvm-objdump: the packed-fp32 guard did not run", file=sys.stderr)
-        return
+        os.remove(lib)
+        raise RuntimeError("no llvm-objdump: the packed-fp32 guard cannot run, refusing to ship an unchecked library")
     with tempfile.TemporaryDirectory() as work:
         shutil.copy(lib, os.path.join(work, "lib.so"))
         subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)

@@ -64,9 +64,8 @@ def test_no_valu_written_sgpr_reaches_a_vmem_instruction_too_early():
     SGPR-base weight-fragment loads of unet_sres2.h / unet_wino.h).  build.py refuses such a library; this is the same scan as a test."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("sgpr_hazard_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "sgpr_hazard_scan.py"))
-    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
-        import pytest
-        pytest.skip("no llvm-objdump in this image")
+    import shutil
+    assert os.path.exists(shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"), "no llvm-objdump: the guard cannot run (a skipped guard is a failed guard)"
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.scan_library(build.build_library(verbose=False)) == []
@@ -74,6 +73,18 @@ def test_no_valu_written_sgpr_reaches_a_vmem_instruction_too_early():
     bad = "0000 <k>:\n\tv_readfirstlane_b32 s11, v6\n\tv_lshlrev_b32_e32 v192, 4, v190\n\tglobal_load_dwordx4 v[130:133], v192, s[10:11]\n"
     assert len(mod.scan(bad)) == 1
     assert mod.scan(bad.replace("\tv_lshlrev_b32_e32 v192, 4, v190\n", "\ts_nop 4\n")) == []
+    # ... and across a back-edge: an SGPR reload at the loop tail, the asm load at the loop head
+    loop = ("0000000000001000 <k>:\n"
+            "\tglobal_load_dwordx4 v[130:133], v192, s[10:11]   // 000000001000: DC000000\n"
+            "\tv_add_u32_e32 v1, v2, v3                          // 000000001008: 68000000\n"
+            "\tv_add_u32_e32 v1, v2, v3                          // 00000000100C: 68000000\n"
+            "\tv_add_u32_e32 v1, v2, v3                          // 000000001010: 68000000\n"
+            "\tv_add_u32_e32 v1, v2, v3                          // 000000001014: 68000000\n"
+            "\tv_add_u32_e32 v1, v2, v3                          // 000000001018: 68000000\n"
+            "\tv_readlane_b32 s11, v6, 3                         // 00000000101C: D2890000\n"
+            "\ts_cbranch_scc1 65528                              // 000000001024: BF85FFF8 <k+0x0>\n")
+    assert len(mod.scan(loop)) == 1
+    assert mod.scan(loop.replace("\tv_readlane_b32 s11, v6, 3 ", "\tv_readlane_b32 s12, v6, 3 ")) == []
 
 
 def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
@@ -85,9 +96,7 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
     import shutil
     import subprocess
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        import pytest
-        pytest.skip("no llvm-objdump in this image")
+    assert os.path.exists(objdump), "no llvm-objdump: the code-object checks cannot run (a skipped guard is a failed guard)"
     path = build.build_library(verbose=False)
     work = str(tmp_path)
     shutil.copy(path, os.path.join(work, "lib.so"))
