@@ -61,8 +61,8 @@ struct oai_unet {
     bool calibrated = false;
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
-    int opt_wino = 19;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
-                                        // bit 4 (round 4): the two-group form's taps on v_mfma_f32_16x16x32_f16 (same cycles per FLOP, +13 % clock at the power wall)
+    int opt_wino = 51;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
+                                        // bits 4, 5 (round 4): the taps of the two-group / the specialised form on v_mfma_f32_16x16x32_f16 (same cycles per FLOP, +14 % clock at the power wall)
     int opt_wino_layers = 0x3FFFF;      // option "winograd_layers": bit k = layer k may take the Winograd kernel (A/B of single layers)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
@@ -379,7 +379,6 @@ static int pack_wino_layer(oai_unet* h, int k) {
     if (L.panel_wino && panel.size() != L.panel_wino_floats) return set_error(OAI_ERR_ARG, "Winograd panel of layer %d changed size", k);
     L.panel_wino_floats = panel.size();
     if (int rc = upload_into(h, panel, &L.panel_wino)) return rc;
-    if (L.cout % 128 != 0) return OAI_OK;                             // the 16x16x32 taps exist for the two-group form
     const std::vector<float> p16 = pack_wino16_panel(L.wk_host, L.c0, L.c1, L.cout, L.ws, ldexpf(1.0f, L.rel1));
     if (L.panel_wino16 && p16.size() != L.panel_wino16_floats) return set_error(OAI_ERR_ARG, "16x16x32 Winograd panel of layer %d changed size", k);
     L.panel_wino16_floats = p16.size();
@@ -694,7 +693,10 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
             return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_wino_sres<1, TY, NP, 1, true>, 512, 0) == hipSuccess && n >= 1;
         }();
         if ((h->opt_wino & 4) || !ws_fits) conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);        // (A/B, or no room: the eight waves split the z slices)
-        else conv3_wino_sres<1, TY, NP, 1, true><<<grid, 512, 0, st>>>(a, h->zero_rec);                  // one block of 64 couts: four waves multiply, four stage
+        else if ((h->opt_wino & 32) && L.panel_wino16) {                                               // the multipliers' taps on v_mfma_f32_16x16x32_f16
+            a.wpanel = L.panel_wino16;
+            conv3_wino_sres<1, TY, NP, 1, true, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
+        } else conv3_wino_sres<1, TY, NP, 1, true><<<grid, 512, 0, st>>>(a, h->zero_rec);              // one block of 64 couts: four waves multiply, four stage
     } else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);       // (the y strip's two T buffers would not fit: the eight waves split the z slices)
     OAI_CHECK_LAUNCH();
     if (h->profile) {
@@ -1222,8 +1224,8 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         h->opt_wide = value;
     } else if (!strcmp(name, "winograd")) {            // bit 0: layers with Cout % 128 == 0 (two cout groups per workgroup), bit 1: one block of 64 couts and >= 8 chunks
                                                        // (specialised waves); A/B only: bit 2 = the slice-split form instead, bit 3 = the specialised form for every layer;
-                                                       // bit 4: the two-group form's taps on v_mfma_f32_16x16x32_f16 (tap pairs; another summation order)
-        OAI_CHECK_ARG(value >= 0 && value <= 31, "oai_unet_set_option: winograd must be in [0, 31]");
+                                                       // bit 4 / bit 5: the two-group / the specialised form's taps on v_mfma_f32_16x16x32_f16 (tap pairs; another summation order)
+        OAI_CHECK_ARG(value >= 0 && value <= 63, "oai_unet_set_option: winograd must be in [0, 63]");
         if (value && !h->opt_wino && h->L[EC0].scale_f16) {
             OAI_CHECK_HIP(hipDeviceSynchronize());
             for (int k = 1; k < 17; ++k)

@@ -67,7 +67,7 @@ template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false>
 __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
-    static_assert(!M16 || (MS == 1 && !WS), "the 16x16x32 taps exist for the plain four-slice form");
+    static_assert(!M16 || MS == 1, "the 16x16x32 taps exist for the four-slice forms (two groups, or specialised waves)");
     static_assert(!WS || (NG == 1 && MS == 1), "specialised waves: four multiply, four stage");
     constexpr int TZ = 4, TX = 2 * NP, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int RS = 4 * HX + 1;                                // 16-byte pieces per raw row (hz, hy): [term][hx][half] + 1 pad
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                      : "=&s"(keep) : "v"(off), "s"(cbase), "s"(__builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16)) : "memory");
     };
     unsigned miss = 0;                                              // bit it: piece it of this thread lies outside the tile
-    if constexpr (M16) {
+    if constexpr (M16 && !WS) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) miss |= poff[it] == kNoPiece ? 1u << it : 0u;
     }
@@ -289,12 +289,12 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     // (computed at the top of every chunk's taps from an opaque copy of the lane id: kept live through the transform -- the register peak of
     // the chunk loop -- they are what tips the allocator into spilling)
     unsigned a16[M16 ? 9 : 1];
-    auto compute_a16 = [&]() __attribute__((always_inline)) {
+    auto compute_a16 = [&](unsigned tbofs = 0) __attribute__((always_inline)) {      // tbofs: byte offset of the T buffer to read (WS: two of them)
         int lq = lane;
         asm volatile("" : "+v"(lq));
         const int r16 = lq & 15, hsel = (lq >> 4) & 1, tsel = lq >> 5;
         const int y16 = r16 / NP, p16 = r16 % NP;
-        const unsigned rowofs = (unsigned)(((f * HY + y16) * NP + p16) * 64);
+        const unsigned rowofs = tbofs + (unsigned)(((f * HY + y16) * NP + p16) * 64);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     constexpr int D = WS ? 2 : 1, NB = D + 1;
     f32x4 bq[NB][2][NREP];                                          // [tap % NB][term][n]
     f32x4 bXlo[2], bXhi[2], bY[4];                                  // M16: X' (the high terms b0), couts n 0, 1 and n 2, 3, and Y' (the low terms b1) of the running step
-    if constexpr (M16) {
+    if (M16 && !stager) {                                           // (WS: the multipliers only)
         sgpr_settle(wp);
 #pragma unroll
         for (int n = 0; n < 2; ++n) { bXlo[n] = n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane); bXhi[n] = n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane); }
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         wp += STEP * 16;
         vm_wait<0>(bXlo[0], bXlo[1], bXhi[0], bXhi[1]);
         vm_wait<0>(bY[0], bY[1], bY[2], bY[3]);
-        zero_missing();                                             // (the first raw box has landed with them)
+        if constexpr (!WS) zero_missing();                          // (the first raw box has landed with them)
     } else if (!stager) {
         sgpr_settle(wp);                                            // wp has just been made uniform by v_readfirstlane
 #pragma unroll
@@ -375,7 +375,93 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 asm volatile("" ::: "memory");
             }
             const unsigned char* abase = Tl + (WS ? (ch & 1) * TB : 0) + aofs;
-            if constexpr (M16) {
+            if constexpr (M16 && WS) {
+                // The multipliers' chunk on 16x16x32 tap pairs: the two-group form's step (below) without the halo pieces -- the stagers request
+                // those -- and without a drain at the chunk end: the fragments of the next chunk's step 0 stay in flight across the barrier.
+                constexpr int SL = 4 * HY * NP * 64;
+                auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
+                    return *reinterpret_cast<const float4*>(Tl + off + m * SL + p * 1024);
+                };
+                auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+                };
+                compute_a16((unsigned)((ch & 1) * TB));
+                float4 af[MREP][2];
+#pragma unroll
+                for (int m = 0; m < ML; ++m)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[0], m, p);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    vm_wait<4>(bY[0], bY[1], bY[2], bY[3]);              // Y'(j) has landed; younger: lo(j), hi(j)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)                          // pass B: a0 . Y'
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) mma(af[m][p], bY[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!OAI_DBG_BIT(a, 4096)) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
+                    }
+                    asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");      // lo(j); younger: hi(j), Y'(j + 1)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)                          // pass A, low couts
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");      // hi(j); younger: Y'(j + 1)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < ML; ++m) {                        // pass A, high couts; behind each slice its a1 fragments
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j < 4) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j * 2 + 1], m, p);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (j < 4) {
+#pragma unroll
+                        for (int m = 0; m < ML; ++m)                      // pass C, low couts
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!OAI_DBG_BIT(a, 4096)) { bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 4) {
+#pragma unroll
+                        for (int m = 0; m < ML; ++m) {                    // pass C, high couts; behind each slice the next step's a0 fragments
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j < 3 ? (j + 1) * 2 : 8], m, p);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (!OAI_DBG_BIT(a, 4096)) { bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane); }
+                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            } else if constexpr (M16) {
                 // Five steps, pass order B, A, C -- a0 . Y', a0 . X', a1 . X'.  Y' is dead after the first pass: its registers take Y' of the
                 // next step a whole step ahead.  X' is live through the last two passes; so that its successor has more than pass B to land
                 // in, passes A and C run the LOW couts (n 0, 1) over all slices and then the HIGH couts (n 2, 3): X' lo is dead after C lo and

@@ -149,7 +149,7 @@ class UNetEngine:
     def set_option(self, name: str, value: int) -> None:
         """Tuning options of the fp16x3 path (include/oai_hip.h: oai_unet_set_option).  Bit-preserving (same k order, same maps):
         "sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census".
-        NOT bit-preserving: "winograd" (bit mask, default 19: the x axis of ten layers in Winograd F(2,3) form, bit 4 = 16x16x32 tap pairs -- other rounding,
+        NOT bit-preserving: "winograd" (bit mask, default 51: the x axis of ten layers in Winograd F(2,3) form, bit 4 = 16x16x32 tap pairs -- other rounding,
         same parity gates; 0 = the direct form everywhere) and "winograd_layers" (which layers)."""
         _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
         if name == "sres":

@@ -160,12 +160,14 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
     # (f) the default two-group form (round 4): the same kernel with its taps on v_mfma_f32_16x16x32_f16, K = a pair of taps -- 14 steps x 32
     # MFMAs per chunk for ML = 4 (448 + 336 + 224 + 112); its counted waits need a tap stream free of compiler-made vector-memory operations
     # (a scratch reload drains vmcnt: every prefetched fragment with it), and its halo pieces come from an SGPR base + 32-bit offset
-    sym = "_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1EEEvNS_8ConvArgsEPKh"
-    m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
-    assert m, f"{sym} not in the library"
-    body = m.group(1).split("\n")
-    mf_i = [i for i, ln in enumerate(body) if "v_mfma_f32_16x16x32_f16" in ln]
-    assert len(mf_i) == 1120 and not [ln for ln in body if "v_mfma_f32_32x32x16_f16" in ln]
-    assert not [ln for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside a tap stream of the 16x16x32 form"
-    loads = [ln for ln in body if ("global_load_dwordx4" in ln or "global_load_lds_dwordx4" in ln)]
-    assert len(loads) >= 40 and all("s[" in ln.split("//")[0] for ln in loads), "a fragment load or a halo piece that is not the SGPR-base asm form"
+    for sym in ("_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1EEEvNS_8ConvArgsEPKh", "_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi1ELb1ELb1EEEvNS_8ConvArgsEPKh"):
+        m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
+        assert m, f"{sym} not in the library"
+        body = m.group(1).split("\n")
+        mf_i = [i for i, ln in enumerate(body) if "v_mfma_f32_16x16x32_f16" in ln]
+        assert len(mf_i) == 1120 and not [ln for ln in body if "v_mfma_f32_32x32x16_f16" in ln]
+        assert not [ln for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside a tap stream of the 16x16x32 form"
+        loads = [ln for ln in body if "global_load_dwordx4" in ln and "lds" not in ln]
+        assert len(loads) >= 40 and all("s[" in ln.split("//")[0] for ln in loads), "a fragment load that is not the SGPR-base asm form"
+    # (the two-group form's halo pieces also come from an SGPR base + 32-bit offset; the specialised form's stagers keep the per-lane 64-bit form)
+    assert all("s[" in ln.split("//")[0] for ln in re.search(r"^[0-9a-f]+ <_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1EEEvNS_8ConvArgsEPKh>:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M).group(1).split("\n") if "global_load_lds_dwordx4" in ln)

@@ -171,7 +171,7 @@ def test_an_overflowing_transformed_input_of_the_winograd_form_raises_the_flag()
     x = torch.full((1, 1, 32, 64, 64), 0.7)
     EC3, bit = 3, 1
     flags = {}
-    for wino in (0, 3, 19):                                     # direct, Winograd on 32x32x16, Winograd on 16x16x32 tap pairs (the default)
+    for wino in (0, 3, 51):                                     # direct, Winograd on 32x32x16, Winograd on 16x16x32 tap pairs (the default)
         eng = UNetEngine(sd, precision="fp16x3")
         eng.set_option("winograd", wino)
         eng.forward_tiles(x)                                   # calibrates: every layer's maximum in [2^10, 2^11) (and leaves the census empty)
@@ -186,7 +186,7 @@ def test_an_overflowing_transformed_input_of_the_winograd_form_raises_the_flag()
         assert 32752.0 < eng.census()[EC3] <= 65504.0
         flags[wino] = eng.range_flag()
     assert flags[0] & bit == 0, "the direct form has nothing to report: every stored activation fits fp16"
-    assert flags[3] & bit == bit and flags[19] & bit == bit, "an overflowing Winograd input must raise the overflow bit"
+    assert flags[3] & bit == bit and flags[51] & bit == bit, "an overflowing Winograd input must raise the overflow bit"
 
 
 # ---- the calibration belongs to the checkpoint (VERDICT r3 weak #8 / ADVICE r3 medium) ---------------------------------------------
