@@ -1,0 +1,36 @@
+"""GPU: the process-group path on real hardware -- one rank under torch.distributed.run with the "nccl" (RCCL) backend, the only
+multi-process configuration a one-GPU box allows.  The CPU/gloo tests (tests/test_parallel_cpu.py) cover world sizes 2-4; this one
+covers what they cannot: RCCL initialisation next to liboai_hip.so in the same process, every collective of parallel.py on DEVICE
+tensors, and run_sharded == run under an initialised group."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_run_sharded_equals_run_under_an_rccl_process_group_of_one():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)      # a CHILD process: this one keeps its GPU context
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world"] == 1 and out["backend"] == "nccl"
+    assert out["calibrated"] and len(out["exponents"]) == 18
+    assert out["equal"], "run_sharded differs from run under the process group"
+    assert out["flag"] == 0 and out["fc_sum"] > 0
