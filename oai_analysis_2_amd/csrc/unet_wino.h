@@ -37,6 +37,13 @@
 // -- not on the block grid, the batch or the launch box: results do not depend on how tiles are batched.
 #pragma once
 #include "unet_sres2.h"
+// Experimental builds only (build_library(extra_flags=["-DOAI_EXP=<bits>"]) into build/exp/: timing of the epilogue's parts, results wrong):
+// 1 no copy-out stores, 2 no fused pool, 4 no output transform / image (stores of stale LDS) -- CAUTION: bits 1 and 4 leave the activations of later layers
+// zero / stale, and an MFMA loop on such data clocks higher: they price nothing downstream; 16 every copy-out store issued TWICE (same data, same address:
+// the marginal cost of the stores with all data real), 32 plain instead of non-temporal stores.  Never defined in the shipped library.
+#ifndef OAI_EXP
+#define OAI_EXP 0
+#endif
 
 namespace oai {
 
@@ -794,7 +801,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             const int oz = oz0 + F;
             const bool zok = oz >= blo[0] && oz < bhi[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < ((OAI_EXP & 4) ? 0 : 16); ++r) {
                 // C/D row and 16-cout record of element r: 32x32 -- register r of the tile; 16x16 -- element i = r & 3 of tile (p, q) = (r >> 3, (r >> 2) & 1)
                 const int rr = M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int qrec = M16 ? (r >> 2) & 1 : row >> 4;
@@ -834,16 +841,24 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 for (int it = 0; it < EIT; ++it) {
                     const int zc = it >> 1, yc = (it & 1) * (32 / TX);
                     const int ozc = oz0 + zc, oy = oyl + yc;
-                    if (cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
+                    if (!(OAI_EXP & 1) && cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
                         const unsigned uni = (unsigned)(((ozc * a.H + oy0 + yc) * a.W + ox0) * 64);                  // wave-uniform
                         float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
                         const float4 val = *reinterpret_cast<const float4*>(xb + (it * 256 + gtid) * 16);
-                        __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
-                        __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                        if constexpr ((OAI_EXP & 32) != 0) *dstp = val;
+                        else {
+                            __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                            __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                        }
+                        if constexpr ((OAI_EXP & 16) != 0) {
+                            asm volatile("" ::: "memory");
+                            __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                            __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                        }
                     }
                 }
             }
-            if constexpr (TY == 8 && NP == 4) if (a.pool_out) {       // (main shape only: the host asks for it where the box is whole blocks of it)
+            if constexpr (TY == 8 && NP == 4) if (a.pool_out && !(OAI_EXP & 2)) {       // (main shape only: the host asks for it where the box is whole blocks of it)
                 // MaxPool3d(2) fused (ec3 / ec5; networks.py:117,122), from the block's image: thread = (pooled voxel, 4 channels of one of the two
                 // 16-channel records); the pooled record keeps the (h0, h1) PAIR of the window's largest joined value -- the rule of
                 // maxpool2_sres_kernel (on equal values the pair with the larger h0: what splitting the fp32 maximum would have produced).
