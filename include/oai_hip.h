@@ -211,12 +211,13 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *                       block from ONE double-buffered halo box (unet_sres2.h); 1 = launches of >= 1024 workgroups, 2 = always
  *   "shared_enc" 0|1 (1) oai_segment_tiles computes ec0 -> ec1 once over the padded volume + a 2-voxel shell per tile (needs the workspace
  *                       of oai_segment_workspace_bytes; geometries it does not fit fall back to per-tile computation)
- *   "winograd" 0..63 (51) NOT bit-preserving (same precision class, other rounding points; probabilities within ~2e-6 of the direct
+ *   "winograd" 0..63 (19) NOT bit-preserving (same precision class, other rounding points; probabilities within ~2e-6 of the direct
  *                       form's): the plain k3 layers (no fused ec0 / pool / head) run conv3_wino_sres (unet_wino.h), the x axis in Winograd
  *                       F(2,3) form = 2/3 of the MFMAs.  bit 0: layers with Cout % 128 == 0, bit 1: layers with one block of 64 couts
- *                       and >= 8 input chunks (dc2); 0 = the direct kernels everywhere; bits 2, 3: A/B of alternative kernel forms; bits 4, 5 (round 4): the
- *                       two-group / the specialised form's taps on v_mfma_f32_16x16x32_f16 with K = a pair of taps (same cycles per FLOP, the shape the chip clocks
- *                       ~13 % higher at the power wall; another summation order, same gates).  A value depends on the parity of its voxel's x only -- not on blocks, strips
+ *                       and >= 8 input chunks (dc2); 0 = the direct kernels everywhere; bits 2, 3: A/B of alternative kernel forms; bit 4 (round 4): the
+ *                       two-group form's taps on v_mfma_f32_16x16x32_f16 with K = a pair of taps (same cycles per FLOP, the shape the chip clocks
+ *                       ~13 % higher at the power wall; another summation order, same gates; bit 5, A/B only: the same for the specialised 64-cout form, whose y strips keep 32x32x16 -- with it a
+ *                       voxel's bits depend on the launch shape that covers it).  Without bit 5 a value depends on the parity of its voxel's x only -- not on blocks, strips
  *                       or batching.  "winograd_layers" (mask, all): bit k = layer k may take it (A/B of single layers)
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)

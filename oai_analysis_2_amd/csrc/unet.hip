@@ -61,8 +61,10 @@ struct oai_unet {
     bool calibrated = false;
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
-    int opt_wino = 51;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
-                                        // bits 4, 5 (round 4): the taps of the two-group / the specialised form on v_mfma_f32_16x16x32_f16 (same cycles per FLOP, +14 % clock at the power wall)
+    int opt_wino = 19;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
+                                        // bit 4 (round 4): the taps of the two-group form on v_mfma_f32_16x16x32_f16 (same cycles per FLOP, +14 % clock at the power wall);
+                                        // bit 5 (A/B only, NOT for production): the same for the specialised 64-cout form -- its y strips keep the 32x32x16 slice-split
+                                        // form, i.e. another summation order: a voxel's bits would depend on which launch shape covers it, hence on batching
     int opt_wino_layers = 0x3FFFF;      // option "winograd_layers": bit k = layer k may take the Winograd kernel (A/B of single layers)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)

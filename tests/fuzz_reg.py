@@ -56,15 +56,20 @@ for case in range(6):
     print(f"normalize n={n} pct=({lo:.2f},{hi:.2f}): equal={np.array_equal(got, ref)} maxdiff={np.abs(got - ref).max():.2e}")
     assert np.abs(got - ref).max() < 1e-6
 
-# ---- one ICON direction on random network shapes (each low-resolution axis >= 17)
-for case in range(2):
-    net = tuple(int(2 * rng.integers(17, 26)) for _ in range(3))
-    sd = make_icon_state_dict(case, 0.1)
+# ---- one ICON direction on random network shapes and step trees (each grid a U-Net runs on needs every axis >= 17)
+TREES = ["3step", "4step", "multires", "multires4", ("two", ("down", ("two", ("down", "u"), ("down", "u"))), ("two", "u", "u"))]
+for case in range(5):
+    tree = TREES[case % len(TREES)]
+    deep = tree in ("multires", "multires4") or not isinstance(tree, str)
+    lo = 34 if deep else 17
+    net = tuple(int(2 * rng.integers(lo, lo + 6)) for _ in range(3))
+    sd = make_icon_state_dict(case, 0.1, tree)
     a, b = make_volume(case, net), make_volume(case + 5, net)
     ref = oicon.regis_net_direction(torch.from_numpy(a)[None, None], torch.from_numpy(b)[None, None], sd)[0].numpy()
-    got = IconEngine(sd, net).phi(dev(a), dev(b)).cpu().numpy()
+    eng = IconEngine(sd, net)
+    got = eng.phi(dev(a), dev(b)).cpu().numpy()
     d_ref = ref - identity_map(net)
     rel = np.abs(got - ref).max() / np.abs(d_ref).max()
-    print(f"ICON net {net}: displacement rel err {rel:.2e}")
+    print(f"ICON net {net} tree {eng.tree.describe()}: displacement rel err {rel:.2e}")
     assert rel < 1e-4
 print("all fuzz cases passed")

@@ -171,7 +171,7 @@ def test_an_overflowing_transformed_input_of_the_winograd_form_raises_the_flag()
     x = torch.full((1, 1, 32, 64, 64), 0.7)
     EC3, bit = 3, 1
     flags = {}
-    for wino in (0, 3, 51):                                     # direct, Winograd on 32x32x16, Winograd on 16x16x32 tap pairs (the default)
+    for wino in (0, 3, 19):                                     # direct, Winograd on 32x32x16, Winograd on 16x16x32 tap pairs (the default)
         eng = UNetEngine(sd, precision="fp16x3")
         eng.set_option("winograd", wino)
         eng.forward_tiles(x)                                   # calibrates: every layer's maximum in [2^10, 2^11) (and leaves the census empty)
@@ -186,7 +186,7 @@ def test_an_overflowing_transformed_input_of_the_winograd_form_raises_the_flag()
         assert 32752.0 < eng.census()[EC3] <= 65504.0
         flags[wino] = eng.range_flag()
     assert flags[0] & bit == 0, "the direct form has nothing to report: every stored activation fits fp16"
-    assert flags[3] & bit == bit and flags[51] & bit == bit, "an overflowing Winograd input must raise the overflow bit"
+    assert flags[3] & bit == bit and flags[19] & bit == bit, "an overflowing Winograd input must raise the overflow bit"
 
 
 # ---- the calibration belongs to the checkpoint (VERDICT r3 weak #8 / ADVICE r3 medium) ---------------------------------------------
@@ -274,6 +274,12 @@ def test_calibrate_step_refuses_an_empty_census_and_census_off_needs_a_calibrati
     eng = UNetEngine(make_unet_state_dict(seed=0, width_div=4), precision="fp16x3")
     with pytest.raises(_lib.OaiError, match="census 0 needs a calibrated handle"):
         eng.set_option("census", 0)
-    with pytest.raises(_lib.OaiError, match="census is empty"):
-        eng.calibrate(lambda: None)                                # no pass was queued: nothing to calibrate from
+    import ctypes as C
+    more = C.c_int(0)
+    assert eng.lib.oai_unet_calibrate_step(eng._h, torch.cuda.current_stream().cuda_stream, C.byref(more)) != 0      # no pass was queued: nothing to calibrate from
+    assert b"census is empty" in eng.lib.oai_last_error()
+    assert eng.act_exponents() == ([0] * 18, False)                # ... and the handle is NOT marked calibrated (it used to be, with all-zero exponents)
+    # the engine turns that into a warning for networks whose layers record no census at all (widths that are not multiples of 16)
+    with pytest.warns(UserWarning, match="records no range census"):
+        assert eng.calibrate(lambda: None) == 0
     assert eng.act_exponents() == ([0] * 18, False)
