@@ -226,7 +226,11 @@ class UNetEngine:
         if doc.get("weights_sha256") != self.weights_sha256:
             warnings.warn(f"fp16x3 calibration file {path} belongs to other weights: ignoring it")
             return False
-        self.set_act_exponents(exps)
+        try:
+            self.set_act_exponents(exps)           # (the library checks the range: an edited file with wild exponents is refused there)
+        except _lib.OaiError as exc:
+            warnings.warn(f"fp16x3 calibration file {path} holds exponents the library refuses ({exc}): ignoring it")
+            return False
         self.calibration_source = "file"
         return True
 
