@@ -95,6 +95,19 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     unsigned char* const raw = lds + NTB * TB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef OAI_DIAG
+    // phase stamps (scripts/stamp_wino.py; s_memrealtime: 100 MHz): [0] prologue, [1] chunk loop, [2] epilogue, [8] waves; [10] / [11] = earliest start /
+    // latest end of any wave (the span of the launch: span x CUs - the workgroups' own time = what a CU spends between workgroups + the tail)
+    // [3] exchange (send, receive, three barriers), [4] output transform + image writes + barrier, [5] copy-out (+ fused pool) -- parts of [2], both halves
+    unsigned long long wst[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, wep[3] = {0, 0, 0}, wlast = 0;
+#define OAI_WSTAMP(i) do { if (a.stamps) wst[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define OAI_WEP0() do { if (a.stamps) wlast = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define OAI_WEP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); wep[i] += now_ - wlast; wlast = now_; } } while (0)
+#else
+#define OAI_WSTAMP(i) do { } while (0)
+#define OAI_WEP0() do { } while (0)
+#define OAI_WEP(i) do { } while (0)
+#endif
     const int grp = (MS == 2 || WS) ? 0 : wave >> 2, zp = MS == 2 ? wave >> 2 : 0, f = wave & 3, gtid = tid & 255;
     const bool stager = WS && __builtin_amdgcn_readfirstlane(wave) >= 4;      // WS: waves 4-7 stage, waves 0-3 multiply (a scalar condition: the branches on it are uniform)
     int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
@@ -366,6 +379,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         if (nchunks > 1) stage_request(1);
     }
     __syncthreads();
+    OAI_WSTAMP(1);
 
     auto run_chunks = [&](auto ml_tag) __attribute__((always_inline)) {
         constexpr int ML = decltype(ml_tag)::value;
@@ -732,6 +746,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     }
 
     if constexpr (D > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // fragments requested past the last tap: never used, drained before their registers are reused
+    OAI_WSTAMP(2);
     // ---- epilogue
     constexpr int TV = TZ * TY * TX;                                // 256 voxels
     constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
@@ -764,6 +779,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         constexpr int F = decltype(ftag)::value;
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
+            OAI_WEP0();
             __syncthreads();                                          // T reads / the previous half's copy-out are done
             // send: slice m of frequency F to wave m
 #pragma unroll
@@ -795,6 +811,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 }
             }
             __syncthreads();                                          // everybody has its frequencies: the buffer becomes the output image
+            OAI_WEP(0);
             const int ccol = M16 ? col16 : row;                       // cout column inside its 16-column (M16) / 32-column tile
             const bool odd = ccol & 1;
             const unsigned sel = odd ? 0x03020706u : 0x05040100u;
@@ -830,6 +847,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 *reinterpret_cast<unsigned*>(dst + 32) = w_lo;
             }
             __syncthreads();
+            OAI_WEP(1);
             {
                 const int t5 = gtid >> 3, q = gtid & 7;
                 const int x_lane = t5 % TX, y_lane = t5 / TX;
@@ -890,6 +908,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                     *reinterpret_cast<u16x4*>(dst + 32) = ml;
                 }
             }
+            OAI_WEP(2);
         }
     };
     // MS = 2: wave (zp, F) holds frequency F of the units e = (local slice s, cout half n) = 2 s + n of its slice pair; it finishes unit F.
@@ -995,6 +1014,19 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     }
     if (nonfinite) atomicOr(a.range_flag, 1);
     census_note(a.census, a.range_flag, vmax);
+#ifdef OAI_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the stamped epilogue includes the round trip of its last stores)
+    OAI_WSTAMP(3);
+    if (a.stamps && lane == 0) {
+        atomicAdd(a.stamps + 0, wst[1] - wst[0]); atomicAdd(a.stamps + 1, wst[2] - wst[1]); atomicAdd(a.stamps + 2, wst[3] - wst[2]);
+        atomicAdd(a.stamps + 3, wep[0]); atomicAdd(a.stamps + 4, wep[1]); atomicAdd(a.stamps + 5, wep[2]);
+        atomicAdd(a.stamps + 8, 1ull);
+        atomicMax(a.stamps + 10, ~wst[0]); atomicMax(a.stamps + 11, wst[3]);   // [10] holds the complement of the earliest start
+    }
+#endif
+#undef OAI_WSTAMP
+#undef OAI_WEP0
+#undef OAI_WEP
 }
 
 }  // namespace oai
