@@ -755,6 +755,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     const int nco = (a.Cout + 15) / 16;
     float vmax = 0.0f;
     bool nonfinite = false;                                         // an output inside the box that is inf / NaN (an overflowed t): fmaxf would drop the NaN silently
+    unsigned umax = 0;                                              // (MS = 1: the same as the largest |v| BIT PATTERN inside the box -- NaN > inf > every finite value as unsigned)
+    const float relu_floor = a.relu ? 0.0f : -__builtin_inff();
     // this lane's cout column: lane & 31 of the 32-cout half n -- M16: columns 16 q + (lane & 15), q = 0, 1 (element (p, q, i) = r of the tile)
     const int col16 = lane & 15, rq16 = lane >> 4;
     float scv[NREP][M16 ? 2 : 1], shv[NREP][M16 ? 2 : 1];
@@ -777,6 +779,23 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     // wave F (= frequency F during the taps) finishes z slice F
     auto finish = [&](auto ftag) __attribute__((always_inline)) {
         constexpr int F = decltype(ftag)::value;
+        // Which of this lane's 16 x 2 outputs lie inside the tile's box: ONE mask register, made once per block.  (As compares inside the loop below the
+        // same tests were ~100 SGPR-pair mask operations per cout half, enough of them live at once that the compiler spilled SGPRs through
+        // v_writelane / v_readlane: 1450 instructions per half where ~600 do the work.  Cout % 64 == 0 for every layer of this kernel: no cout test.)
+        unsigned okmask = 0;
+        {
+            const bool zok = oz0 + F >= blo[0] && oz0 + F < bhi[0];
+            const unsigned ylen = (unsigned)(bhi[1] - blo[1]), xlen = (unsigned)(bhi[2] - blo[2]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ty = rr / NP, tx = 2 * (rr % NP);
+                const bool yok = (unsigned)(oy0 + ty - blo[1]) < ylen;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) okmask |= (yok && (unsigned)(ox0 + tx + e - blo[2]) < xlen ? 1u : 0u) << (2 * r + e);
+            }
+            okmask = zok ? okmask : 0u;
+        }
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
             OAI_WEP0();
@@ -812,31 +831,30 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
             __syncthreads();                                          // everybody has its frequencies: the buffer becomes the output image
             OAI_WEP(0);
+            unsigned om = okmask;
+            asm volatile("" : "+v"(om));                              // (per half: otherwise the compiler turns the bit tests into 32 compare masks in the first half and keeps them for the second)
             const int ccol = M16 ? col16 : row;                       // cout column inside its 16-column (M16) / 32-column tile
             const bool odd = ccol & 1;
             const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-            const int oz = oz0 + F;
-            const bool zok = oz >= blo[0] && oz < bhi[0];
 #pragma unroll
             for (int r = 0; r < ((OAI_EXP & 4) ? 0 : 16); ++r) {
                 // C/D row and 16-cout record of element r: 32x32 -- register r of the tile; 16x16 -- element i = r & 3 of tile (p, q) = (r >> 3, (r >> 2) & 1)
                 const int rr = M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int qrec = M16 ? (r >> 2) & 1 : row >> 4;
-                const bool cvalid = cb * 64 + n * 32 + qrec * 16 + (ccol & 15) < nco * 16;
                 const float sc = scv[n][M16 ? (r >> 2) & 1 : 0], sh = shv[n][M16 ? (r >> 2) & 1 : 0];
                 unsigned char* lrow = xb + qrec * 64 + ((ccol & 15) >> 1) * 4;
                 const int ty = rr / NP, tx = 2 * (rr % NP);
                 const float y0 = (M[0][r] + M[1][r]) + M[2][r];
                 const float y1 = (M[1][r] - M[2][r]) - M[3][r];
                 float v[2] = {y0 * sc + sh, y1 * sc + sh};
-                const int oy = oy0 + ty;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int ox = ox0 + tx + e;
-                    const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
-                    nonfinite |= ok && !(fabsf(v[e]) <= 3.0e38f);      // (before the ReLU: fmaxf(NaN, 0) = 0)
-                    if (a.relu) v[e] = fmaxf(v[e], 0.0f);
-                    v[e] = ok ? v[e] : 0.0f;                           // voxels outside the box are never copied out
+                    // voxels outside the box are never copied out: their value is 0 (bitwise AND with the sign-extended mask bit) -- for the census, the
+                    // finiteness test (before the ReLU: fmaxf(NaN, 0) = 0) and the fused pool
+                    const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)om, 2 * r + e, 1);      // 0 or ~0 (v_bfe_i32: no compare, no SGPR mask)
+                    const unsigned b = __builtin_bit_cast(unsigned, v[e]) & keep;
+                    umax = max(umax, b & 0x7FFFFFFFu);
+                    v[e] = fmaxf(__builtin_bit_cast(float, b), relu_floor);
                 }
                 vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
                 unsigned w_hi, w_lo;
@@ -1012,7 +1030,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         else if (f == 2) finish2(std::integral_constant<int, 2>{});
         else finish2(std::integral_constant<int, 3>{});
     }
-    if (nonfinite) atomicOr(a.range_flag, 1);
+    if (nonfinite || umax > __builtin_bit_cast(unsigned, 3.0e38f)) atomicOr(a.range_flag, 1);
     census_note(a.census, a.range_flag, vmax);
 #ifdef OAI_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the stamped epilogue includes the round trip of its last stores)
