@@ -634,6 +634,20 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 #pragma unroll
         for (int i = 0; i < 3; ++i) { clo[i] = max(clo[i], sb[i] - a.store_grow); chi[i] = min(chi[i], sb[3 + i] + a.store_grow); }
     }
+    // Which of this lane's 16 C/D rows (voxels of one z slice) lie inside the tile's box in y and x: ONE mask register, made once per block; the z
+    // and cout tests are uniform / per half and select the whole mask.  (As compares inside the loops below the same tests were SGPR-pair mask
+    // operations per value, enough of them live at once that SGPRs were spilled through v_writelane / v_readlane; conv3_wino_sres, round 4.)
+    unsigned okmask = 0;
+    {
+        const unsigned ylen = (unsigned)(bhi[1] - blo[1]), xlen = (unsigned)(bhi[2] - blo[2]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
+            okmask |= ((unsigned)(oy0 + ty - blo[1]) < ylen && (unsigned)(ox0 + tx - blo[2]) < xlen ? 1u : 0u) << r;
+        }
+    }
+    const float relu_floor = a.relu ? 0.0f : -__builtin_inff();
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + row;
@@ -642,12 +656,15 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         const bool odd = row & 1;
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         unsigned char* lrow = lds + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
+        unsigned omn = cvalid ? okmask : 0u;
+        asm volatile("" : "+v"(omn));                                 // (per half: no compare masks carried from the first half to the second)
         __syncthreads();                                              // halo reads / the previous half's copy-out are done
         OAI_STAMPB(n == 0 ? 0 : 2);
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
             const int oz = oz0 + m;
             const bool zok = oz >= blo[0] && oz < bhi[0];
+            const int om = zok ? (int)omn : 0;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {                          // C/D rows r, r+1 = x-adjacent voxels
                 float v[2];
@@ -656,11 +673,9 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 for (int e = 0; e < 2; ++e) {
                     const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * half;
                     const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
-                    const int ox = ox0 + tx, oy = oy0 + ty;
-                    float x = acc[m][n][r + e] * sc + sh;
-                    if (a.relu) x = fmaxf(x, 0.0f);
-                    const bool ok = cvalid && zok && ox >= blo[2] && ox < bhi[2] && oy >= blo[1] && oy < bhi[1];
-                    v[e] = ok ? x : 0.0f;                              // voxels outside the box are never copied out
+                    const float x = fmaxf(acc[m][n][r + e] * sc + sh, relu_floor);
+                    // voxels outside the box are never copied out: 0 (bitwise AND with the sign-extended mask bit: v_bfe_i32, no compare, no SGPR mask)
+                    v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (unsigned)__builtin_amdgcn_sbfe(om, r + e, 1));
                     vox[e] = (m * kTY + ty) * kTX + tx;
                 }
                 vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));  // fp16 range guard (checked once, below)
