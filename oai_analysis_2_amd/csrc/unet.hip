@@ -751,7 +751,7 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
     if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.sc_boxes &&
-        (!a.pool_out || (a.Cout % 128 == 0 && wino_pool_box(box, dims))) && a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && (a.Cout % 128 == 0 || (a.C0 + 15) / 16 + (a.C1 + 15) / 16 >= 8) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
+        (!a.pool_out || (a.Cout % 128 == 0 && a.relu && wino_pool_box(box, dims))) && a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && (a.Cout % 128 == 0 || (a.C0 + 15) / 16 + (a.C1 + 15) / 16 >= 8) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
         return launch_conv3_wino(h, L, a, box, ntiles, st);
     int ny, nx, hr, wr;
     strip_plan(h, box, ny, nx, hr, wr);

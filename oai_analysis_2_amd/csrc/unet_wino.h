@@ -852,9 +852,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                     // voxels outside the box are never copied out: their value is 0 (bitwise AND with the sign-extended mask bit) -- for the census, the
                     // finiteness test (before the ReLU: fmaxf(NaN, 0) = 0) and the fused pool
                     const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)om, 2 * r + e, 1);      // 0 or ~0 (v_bfe_i32: no compare, no SGPR mask)
-                    const unsigned b = __builtin_bit_cast(unsigned, v[e]) & keep;
-                    umax = max(umax, b & 0x7FFFFFFFu);
-                    v[e] = fmaxf(__builtin_bit_cast(float, b), relu_floor);
+                    umax = max(umax, __builtin_bit_cast(unsigned, v[e]) & keep & 0x7FFFFFFFu);
+                    v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, fmaxf(v[e], relu_floor)) & keep);    // (ReLU on the computed value: no canonicalising max in front of it)
                 }
                 vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
                 unsigned w_hi, w_lo;
@@ -902,20 +901,26 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 static_assert(TZ * TY * TX / 8 == 32, "32 pooled voxels x 8 quarter records = the 256 threads of a cout group");
                 const int pv = gtid >> 3, q = gtid & 7;
                 const int px = pv % (TX / 2), py = (pv / (TX / 2)) % (TY / 2), pz = pv / ((TX / 2) * (TY / 2));
-                float mval[4];
                 u16x4 mh, ml;
+                {
+                    // The host takes this kernel for a pooled layer only behind a ReLU: every record is >= +0 (h0 >= +0, h0 + h1 >= +0, no -0: fmaxf(x, +0),
+                    // x - x = +0), and for such values "larger joined value, then larger h0" is the unsigned order of (bits of the joined fp32 : bits of h0)
+                    // -- one 64-bit compare and two selects per candidate instead of three float compares, their mask logic and three selects.  (Equal
+                    // joined value and equal h0 means equal h1.)
+                    unsigned long long mkey[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int vox = ((2 * pz + (k >> 2)) * TY + 2 * py + ((k >> 1) & 1)) * TX + 2 * px + (k & 1);
-                    const unsigned char* rec = xb + vox * 128 + (q >> 2) * 64 + (q & 3) * 8;
-                    const u16x4 h = *reinterpret_cast<const u16x4*>(rec), l = *reinterpret_cast<const u16x4*>(rec + 32);
+                    for (int k = 0; k < 8; ++k) {
+                        const int vox = ((2 * pz + (k >> 2)) * TY + 2 * py + ((k >> 1) & 1)) * TX + 2 * px + (k & 1);
+                        const unsigned char* rec = xb + vox * 128 + (q >> 2) * 64 + (q & 3) * 8;
+                        const u16x4 h = *reinterpret_cast<const u16x4*>(rec), l = *reinterpret_cast<const u16x4*>(rec + 32);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = join2_f16(h[j], l[j]);
-                        const bool better = k == 0 || v > mval[j] ||
-                                            (v == mval[j] && (float)__builtin_bit_cast(_Float16, h[j]) > (float)__builtin_bit_cast(_Float16, mh[j]));
-                        if (better) { mval[j] = v; mh[j] = h[j]; ml[j] = l[j]; }
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, join2_f16(h[j], l[j])) << 32) | ((unsigned)h[j] << 16) | l[j];
+                            mkey[j] = k == 0 ? key : max(mkey[j], key);
+                        }
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { mh[j] = (unsigned short)(mkey[j] >> 16); ml[j] = (unsigned short)mkey[j]; }
                 }
                 const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
                 const int gz = oz0 / 2 + pz, gy = oy0 / 2 + py, gx = ox0 / 2 + px;
