@@ -729,7 +729,10 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         const int t = (iz * a.sc_g[1] + iy) * a.sc_g[2] + ix - a.sc_tile0;
                         if (t < 0 || t >= a.sc_ntiles) continue;
                         const int lz0 = oz0 - iz * a.sc_e[0], ly0 = oy0 - iy * a.sc_e[1], lx0 = ox0 - ix * a.sc_e[2];      // block origin in tile coordinates
-                        const int* sb = a.sc_boxes + 6 * t;
+                        // (constant address space: the box is read by SCALAR loads -- lgkmcnt.  As vector loads each candidate tile's box was waited for
+                        // with vmcnt(0), i.e. behind the round trip of every copy-out store issued so far: stamps had 16 % of ec1 in this loop)
+                        typedef const __attribute__((address_space(4))) int* ciptr;
+                        const ciptr sb = (ciptr)(a.sc_boxes + 6 * t);
                         const int s0z = sb[0] - 1, s0y = sb[1] - 1, s0x = sb[2] - 1, s1z = sb[3] + 1, s1y = sb[4] + 1, s1x = sb[5] + 1;
                         if (sb[3] <= sb[0] || lz0 >= s1z || lz0 + TZ <= s0z || ly0 >= s1y || ly0 + kTY <= s0y || lx0 >= s1x || lx0 + kTX <= s0x) continue;
                         unsigned char* ob = outb + ((size_t)t * nco + cb * 4 + n * 2) * tplane * 64;                         // wave-uniform

@@ -120,10 +120,9 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
         nt = [i for i, ln in enumerate(body) if "global_store_dwordx4" in ln and " nt" in ln]
         assert len(mf) >= 600 and len(nt) >= 32
         between = body[nt[0]:nt[-1] + 1]
-        # (the ec0-fused instantiation also holds the scatter copy-out of the shared encoder pass: per candidate tile it loads that tile's box
-        # -- 6 ints -- and waits for it, once per tile, not per store: a vmcnt(0) within a few lines of such a load is that wait)
-        box_wait = lambda i: any("global_load_dwordx" in ln and "lds" not in ln for ln in between[max(0, i - 14):i])
-        assert not [ln for i, ln in enumerate(between) if "scratch_" in ln or ("vmcnt(0)" in ln and not ("Lb1ELb0EEE" in sym and box_wait(i)))], \
+        # (the ec0-fused instantiation also holds the scatter copy-out of the shared encoder pass: each candidate tile's box -- 6 ints -- is read by
+        # SCALAR loads from the constant address space, i.e. waited for with lgkmcnt: no vector load, no vmcnt wait there either)
+        assert not [ln for ln in between if "scratch_" in ln or "vmcnt(0)" in ln or ("global_load_dword" in ln and "lds" not in ln)], \
             "something waits for memory between the copy-out stores"
         for i0, i1 in zip(mf, mf[1:]):                                   # inside a tap stream (MFMAs a few lines apart; the four ML variants lie far apart)
             if i1 - i0 <= 60:
