@@ -41,12 +41,20 @@ __device__ __forceinline__ float join2_f16(unsigned short hi, unsigned short lo)
 // overflow flag (fp16 cannot hold |x| > 65504: report, never silently inf) and folds the wave's maximum into the layer's census -- 16 words
 // per layer, picked by block id so that the ~10^5 waves of a launch do not queue on one L2 atomic unit.  The census is what
 // oai_unet_calibrate_step turns into per-layer power-of-two activation exponents, and what the range flag's LOW bit is derived from.
-__device__ __forceinline__ void census_note(unsigned* census, int* range_flag, float vmax) {
+// `seen` (census_peek at the start of the block): the word's value as this workgroup saw it -- the atomic is issued only for a larger maximum.
+// After the first blocks of a launch nearly every wave's maximum is below what the word already holds; unconditionally, the ~10^5-10^6 waves
+// of a launch sent one atomic each to the SAME 64-byte line (16 words per layer): 2 % of a pass (option census 0 vs 1, same box).  A stale peek
+// (the scalar cache is invalidated per dispatch; other workgroups raise the word meanwhile) only costs a redundant atomic, never loses a maximum.
+__device__ __forceinline__ unsigned census_peek(const unsigned* census) {
+    typedef const __attribute__((address_space(4))) unsigned* cuptr;
+    return census ? *((cuptr)census + (blockIdx.x & 15)) : 0u;      // wave-uniform: a scalar load
+}
+__device__ __forceinline__ void census_note(unsigned* census, int* range_flag, float vmax, unsigned seen = 0u) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
     if ((threadIdx.x & 63) == 0) {
         if (!(vmax <= 65504.0f)) atomicOr(range_flag, 1);
-        if (census && vmax > 0.0f) atomicMax(census + (blockIdx.x & 15), __float_as_uint(vmax));
+        if (census && vmax > 0.0f && __float_as_uint(vmax) > seen) atomicMax(census + (blockIdx.x & 15), __float_as_uint(vmax));
     }
 }
 
@@ -600,6 +608,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     // the (now idle) halo buffer, 128 B per voxel and cout half, and copied out 16 B per lane: 32 full-width stores per wave.
     OAI_STAMPB(7);
     constexpr int TV = TZ * kTY * kTX;                                // voxels of the block
+    const unsigned seen = census_peek(a.census), seen_first = FIRST ? census_peek(a.first_census) : 0u;      // (here: waited for under the epilogue, short live range)
     constexpr int EIT = TV * 8 / 256;                                 // 16-byte pieces per thread and cout half
     static_assert(TV * 128 <= BUF && (TV * 8) % 256 == 0, "output image must fit the halo buffer");
     static_assert((kTX & (kTX - 1)) == 0 && (kTY & (kTY - 1)) == 0, "power-of-two block");
@@ -833,8 +842,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             }
         }
     }
-    if constexpr (FIRST) census_note(a.first_census, a.range_flag, first_max);
-    census_note(a.census, a.range_flag, vmax);
+    if constexpr (FIRST) census_note(a.first_census, a.range_flag, first_max, seen_first);
+    census_note(a.census, a.range_flag, vmax, seen);
 #ifdef OAI_DIAG
     OAI_STAMP(6);
     OAI_STAMPB(6);
@@ -993,6 +1002,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         const size_t inrow = (size_t)cchunk * 8 * plane * 64 + (q & 3) * 16;
         // this lane's four column scales / shifts, loaded ONCE here: inside the loops below hipcc waits for them with vmcnt(0), which in
         // the second half also drains the first half's sixteen copy-out stores all the way to memory
+        const unsigned seen = census_peek(a.census);
         float scn[4], shn[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -1051,7 +1061,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             }
             OAI_USTAMP(4);
         }
-        census_note(a.census, a.range_flag, vmax);
+        census_note(a.census, a.range_flag, vmax, seen);
 #ifdef OAI_DIAG
         OAI_USTAMP(4);
         if (a.stamps && lane == 0) {

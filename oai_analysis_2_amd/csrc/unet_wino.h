@@ -748,6 +748,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     if constexpr (D > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // fragments requested past the last tap: never used, drained before their registers are reused
     OAI_WSTAMP(2);
     // ---- epilogue
+    const unsigned seen = census_peek(a.census);                    // (waited for under the epilogue)
     constexpr int TV = TZ * TY * TX;                                // 256 voxels
     constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
     unsigned char* const xb = lds + grp * XB;                       // exchange buffer, then output image, of this group
@@ -1036,7 +1037,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         else finish2(std::integral_constant<int, 3>{});
     }
     if (nonfinite || umax > __builtin_bit_cast(unsigned, 3.0e38f)) atomicOr(a.range_flag, 1);
-    census_note(a.census, a.range_flag, vmax);
+    census_note(a.census, a.range_flag, vmax, seen);
 #ifdef OAI_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the stamped epilogue includes the round trip of its last stores)
     OAI_WSTAMP(3);
