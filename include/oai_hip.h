@@ -216,8 +216,8 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *                       F(2,3) form = 2/3 of the MFMAs.  bit 0: layers with Cout % 128 == 0, bit 1: layers with one block of 64 couts
  *                       and >= 8 input chunks (dc2); 0 = the direct kernels everywhere; bits 2, 3: A/B of alternative kernel forms; bit 4 (round 4): the
  *                       two-group form's taps on v_mfma_f32_16x16x32_f16 with K = a pair of taps (same cycles per FLOP, the shape the chip clocks
- *                       ~13 % higher at the power wall; another summation order, same gates; bit 5, A/B only: the same for the specialised 64-cout form, whose y strips keep 32x32x16 -- with it a
- *                       voxel's bits depend on the launch shape that covers it).  Without bit 5 a value depends on the parity of its voxel's x only -- not on blocks, strips
+ *                       ~13 % higher at the power wall; another summation order, same gates); bit 5: the same for the 64-cout layer, all its launch shapes
+ *                       (measured within noise of bit 4 alone: not in the default).  A value depends on the parity of its voxel's x only -- not on blocks, strips
  *                       or batching.  "winograd_layers" (mask, all): bit k = layer k may take it (A/B of single layers)
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)

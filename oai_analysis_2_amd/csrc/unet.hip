@@ -63,8 +63,8 @@ struct oai_unet {
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
     int opt_wino = 19;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
                                         // bit 4 (round 4): the taps of the two-group form on v_mfma_f32_16x16x32_f16 (same cycles per FLOP, +14 % clock at the power wall);
-                                        // bit 5 (A/B only, NOT for production): the same for the specialised 64-cout form -- its y strips keep the 32x32x16 slice-split
-                                        // form, i.e. another summation order: a voxel's bits would depend on which launch shape covers it, hence on batching
+                                        // bit 5: the same for the 64-cout layer (dc2) -- ALL its launch shapes (specialised main blocks and x strip, slice-split y strip:
+                                        // wino_m16_64), so a voxel's bits do not depend on the shape that covers it; measured within noise of bit 4 alone (-0.2 %), not the default
     int opt_wino_layers = 0x3FFFF;      // option "winograd_layers": bit k = layer k may take the Winograd kernel (A/B of single layers)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
@@ -658,6 +658,22 @@ static int launch_conv3_one(const oai_unet* h, const Layer& L, const float* s0, 
     return launch_conv3_shape<4, 8, RX, RY, WY, WX>(h, a, box, ntiles, st, pool_only ? 2 : 0);
 }
 
+// The specialised 64-cout form takes ALL of a CU's LDS (160 KB): asked once whether a workgroup of it (both block shapes, both tap forms) fits this
+// device / driver at all
+static bool wino_ws_fits() {
+    static const bool fits = [] {
+        auto one = [](auto kern) { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 512, 0) == hipSuccess && n >= 1; };
+        return one(conv3_wino_sres<1, 8, 4, 1, true>) && one(conv3_wino_sres<1, 16, 2, 1, true>) &&
+               one(conv3_wino_sres<1, 8, 4, 1, true, true>) && one(conv3_wino_sres<1, 16, 2, 1, true, true>);
+    }();
+    return fits;
+}
+// a 64-cout layer on the 16x16x32 taps (option "winograd" bit 5): its main blocks and x strip run the specialised form's tap-pair variant, its y strip
+// the slice-split form's -- ALL its launch shapes or none: a voxel's bits must not depend on which shape covers it
+static bool wino_m16_64(const oai_unet* h, const Layer& L, int cout) {
+    return cout % 128 != 0 && (h->opt_wino & 32) && !(h->opt_wino & (4 | 8)) && L.panel_wino16 && wino_ws_fits();
+}
+
 // One launch of conv3_wino_sres (unet_wino.h) with blocks of 4 x TY x 2 NP over `box` (box.lo[2] even)
 template <int TY, int NP>
 static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
@@ -689,17 +705,15 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
         conv3_wino_sres<2, TY, NP, 1, false, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
     } else if (ng == 2) conv3_wino_sres<2, TY, NP><<<grid, 512, 0, st>>>(a, h->zero_rec);
     else if constexpr (TY != 4) {
-        // the specialised form takes ALL of a CU's LDS (160 KB): asked once whether a workgroup of it fits this device / driver at all
-        static const bool ws_fits = [] {
-            int n = 0;
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_wino_sres<1, TY, NP, 1, true>, 512, 0) == hipSuccess && n >= 1;
-        }();
-        if ((h->opt_wino & 4) || !ws_fits) conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);        // (A/B, or no room: the eight waves split the z slices)
-        else if ((h->opt_wino & 32) && L.panel_wino16) {                                               // the multipliers' taps on v_mfma_f32_16x16x32_f16
+        if ((h->opt_wino & 4) || !wino_ws_fits()) conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);        // (A/B, or no room: the eight waves split the z slices)
+        else if (wino_m16_64(h, L, a.Cout)) {                                                          // the multipliers' taps on v_mfma_f32_16x16x32_f16
             a.wpanel = L.panel_wino16;
             conv3_wino_sres<1, TY, NP, 1, true, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
         } else conv3_wino_sres<1, TY, NP, 1, true><<<grid, 512, 0, st>>>(a, h->zero_rec);              // one block of 64 couts: four waves multiply, four stage
-    } else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);       // (the y strip's two T buffers would not fit: the eight waves split the z slices)
+    } else if (wino_m16_64(h, L, a.Cout)) {                                          // (the y strip's two T buffers would not fit: the eight waves split the z slices --
+        a.wpanel = L.panel_wino16;                                                     //  on the same tap pairs as the layer's other shapes: one summation order per layer)
+        conv3_wino_sres<1, TY, NP, 2, false, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
+    } else conv3_wino_sres<1, TY, NP, 2><<<grid, 512, 0, st>>>(a, h->zero_rec);
     OAI_CHECK_LAUNCH();
     if (h->profile) {
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));

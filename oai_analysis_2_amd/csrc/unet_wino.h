@@ -74,7 +74,7 @@ template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false>
 __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
-    static_assert(!M16 || MS == 1, "the 16x16x32 taps exist for the four-slice forms (two groups, or specialised waves)");
+    static_assert(!M16 || MS == 1 || (NG == 1 && !WS), "the 16x16x32 taps: the four-slice forms (two groups, or specialised waves) and the slice-split 64-cout form");
     static_assert(!WS || (NG == 1 && MS == 1), "specialised waves: four multiply, four stage");
     constexpr int TZ = 4, TX = 2 * NP, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int RS = 4 * HX + 1;                                // 16-byte pieces per raw row (hz, hy): [term][hx][half] + 1 pad
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             // instructions, no HBM / L2 traffic behind them); scripts/wino_var.sh, profiles/r03_winograd.md, r04_wino_stream.md)
             if constexpr (!WS) {
                 if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
-                if constexpr (M16) compute_a16();                    // behind the transform's register peak, in front of the barrier: under the wait for the slowest wave
+                if constexpr (M16) compute_a16((unsigned)(zp * MREP) * (unsigned)(4 * HY * NP * 64));      // (MS = 2: this wave's slice pair)   behind the transform's register peak, in front of the barrier: under the wait for the slowest wave
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                        // T is complete; the raw box is free for the next chunk's pieces
                 asm volatile("" ::: "memory");
@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             const int slot = F * 3 + (e > F ? e - 1 : e);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 v = {acc[e >> 1][e & 1][4 * j], acc[e >> 1][e & 1][4 * j + 1], acc[e >> 1][e & 1][4 * j + 2], acc[e >> 1][e & 1][4 * j + 3]};
+                const f32x4 v = {acc_el(e >> 1, e & 1, 4 * j), acc_el(e >> 1, e & 1, 4 * j + 1), acc_el(e >> 1, e & 1, 4 * j + 2), acc_el(e >> 1, e & 1, 4 * j + 3)};
                 *reinterpret_cast<f32x4*>(xz + ((slot * 4 + j) * 64 + lane) * 16) = v;
             }
         }
@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         for (int g = 0; g < 4; ++g) {
             if (g == F) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) M[g][r] = acc[S][N][r];
+                for (int r = 0; r < 16; ++r) M[g][r] = acc_el(S, N, r);
             } else {
                 const int slot = g * 3 + (F > g ? F - 1 : F);
 #pragma unroll
@@ -970,18 +970,19 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
         }
         __syncthreads();                                              // both slice pairs have their frequencies: the buffers become the output image
-        const int co = cb * 64 + N * 32 + row;
-        const bool cvalid = co < nco * 16;
-        const float sc = scv[N][0], sh = shv[N][0];
-        const bool odd = row & 1;
+        const int ccol = M16 ? col16 : row;                           // cout column inside its 16-column (M16) / 32-column tile (see finish)
+        const bool odd = ccol & 1;
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-        unsigned char* lrow = lds + (N * 2 + (row >> 4)) * 64 + ((row & 15) >> 1) * 4;
         const int zs = zp * 2 + S;
         const int oz = oz0 + zs;
         const bool zok = oz >= blo[0] && oz < bhi[0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int rr = M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int qrec = M16 ? (r >> 2) & 1 : row >> 4;
+            const bool cvalid = cb * 64 + N * 32 + qrec * 16 + (ccol & 15) < nco * 16;
+            const float sc = scv[N][M16 ? (r >> 2) & 1 : 0], sh = shv[N][M16 ? (r >> 2) & 1 : 0];
+            unsigned char* lrow = lds + (N * 2 + qrec) * 64 + ((ccol & 15) >> 1) * 4;
             const int ty = rr / NP, tx = 2 * (rr % NP);
             const float y0 = (M[0][r] + M[1][r]) + M[2][r];
             const float y1 = (M[1][r] - M[2][r]) - M[3][r];

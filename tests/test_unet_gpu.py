@@ -226,7 +226,7 @@ def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     activations, ec0 as its own launch instead of inside ec1's halo staging, weight fragments through the workgroup's LDS ring, the
     8-wave double-buffered kernel of the Cout % 128 == 0 layers off / forced also for small launches, skip tensors written in full,
     no range census, ec0 -> ec1 per tile instead of once over the padded volume + a shell per tile) accumulate in the same k order: identical stitched maps, and the golden tolerance of the default.
-    "winograd" (the x axis of the plain layers in Winograd F(2,3) form; default 19 = both cout classes, the two-group form on 16x16x32 tap pairs; 3 = both on 32x32x16; bit 5 = A/B only) against the direct form (0): same precision, other rounding points."""
+    "winograd" (the x axis of the plain layers in Winograd F(2,3) form; default 19 = both cout classes, the two-group form on 16x16x32 tap pairs; 3 = both on 32x32x16; bit 5 = the 64-cout layer on them too) against the direct form (0): same precision, other rounding points."""
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
     z = np.load(os.path.join(golden_dir, "segment_small.npz"))
     vol = torch.from_numpy(make_volume(int(z["volume_seed"]), (24, 72, 72))).cuda()
@@ -292,16 +292,19 @@ def test_mask_is_the_fp32_sigmoid_predicate_not_the_sign_test(precision):
     assert (mask > 0.5).any() and not (mask > 0.5).all()
 
 
-def test_maps_do_not_depend_on_batching_or_tile_ranges():
+@pytest.mark.parametrize("wino", [19, 51])
+def test_maps_do_not_depend_on_batching_or_tile_ranges(wino):
     """A voxel's arithmetic depends on the parity of its x only -- not on the batch its tile travels in, the launch box (the union of the
     batch's trimmed boxes), the strip that covers it or the tile range of the call.  Found by tests/fuzz_seg.py in round 4: a kernel form
-    that exists for the main block shape only (option winograd bit 5) gave the strips another summation order, so four of 36 tiles changed
-    bits with the batch size.  Geometry of that case: ragged volume, three z rows, tiles through the shared encoder pass."""
+    that existed for the main block shape only (option winograd bit 5, then) gave the strips another summation order, so four of 36 tiles
+    changed bits with the batch size; since then bit 5 switches ALL launch shapes of the 64-cout layer (51 = the default 19 + bit 5).
+    Geometry of that case: ragged volume, three z rows, tiles through the shared encoder pass."""
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
     tile, ovl, shape = (24, 40, 64), (6, 4, 8), (28, 66, 154)
     crop = (ovl[0], ovl[2], ovl[1])
     v = torch.from_numpy(make_volume(200, shape)).cuda()
     eng = UNetEngine(make_unet_state_dict(seed=50, width_div=1), precision="fp16x3")
+    eng.set_option("winograd", wino)
     st = lambda b: eng.stitch(b, shape, tile, ovl, crop)
     ref = st(eng.segment_tiles(v, tile, ovl, None, 2, 6, crop))
     for batch in (1, 4, 12, 36):
