@@ -49,9 +49,25 @@ __device__ __forceinline__ unsigned census_peek(const unsigned* census) {
     typedef const __attribute__((address_space(4))) unsigned* cuptr;
     return census ? *((cuptr)census + (blockIdx.x & 15)) : 0u;      // wave-uniform: a scalar load
 }
+// maximum of a NON-NEGATIVE (or NaN) value over the wave, wave-uniform: six DPP steps on the VALU (quad swaps, row mirrors, row broadcasts: lane 63
+// ends up with the total) and one v_readlane -- __shfl_xor is six serial ds_bpermute round trips through the LDS crossbar at the very end of a block.
+// (Lanes a masked step does not write keep their value -- update_dpp's `old` operand is the value itself.  fmaxf drops a NaN, so a NaN is folded in
+// as +inf first: the overflow test below sees it either way.)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = v == v ? v : __builtin_inff();
+    auto step = [](float x, auto ctrl, auto rmask) __attribute__((always_inline)) {
+        return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xF, false)));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});       // quad_perm 1,0,3,2
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});       // quad_perm 2,3,0,1
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});      // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});      // row_mirror: every lane of a row holds the row's maximum
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});      // row_bcast15 into rows 1, 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});      // row_bcast31 into rows 2, 3: lane 63 = the wave's maximum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ void census_note(unsigned* census, int* range_flag, float vmax, unsigned seen = 0u) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    vmax = wave_max_nonneg(vmax);
     if ((threadIdx.x & 63) == 0) {
         if (!(vmax <= 65504.0f)) atomicOr(range_flag, 1);
         if (census && vmax > 0.0f && __float_as_uint(vmax) > seen) atomicMax(census + (blockIdx.x & 15), __float_as_uint(vmax));
