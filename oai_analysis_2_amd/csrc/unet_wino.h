@@ -717,6 +717,50 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     };
     const int mlb = m_lo == 0 ? m_hi : TZ;                          // live z slices of the block (workgroup-uniform) ...
     const int ml = min(MREP, max(0, mlb - zp * MREP));              // ... and of this wave (wave-uniform; MS = 2: the upper pair of a 1- or 2-slice block idles through the taps)
+    // copy-out of cout half n of the block's output image (LDS, 128 B per voxel) to the output tensor: pieces [it0, it1) of this thread
+    constexpr int TV = TZ * TY * TX;                                // 256 voxels
+    constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
+    unsigned char* const xb = lds + grp * XB;                       // exchange buffer, then output image, of this group
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+    const int nco = (a.Cout + 15) / 16;
+    auto copy_out = [&](int n, int it0, int it1, const int (&clo)[3], const int (&chi)[3]) __attribute__((always_inline)) {
+        const int t5 = gtid >> 3, q = gtid & 7;
+        const int x_lane = t5 % TX, y_lane = t5 / TX;
+        const bool cok = cb * 4 + n * 2 + (q >> 2) < nco;
+        unsigned char* ob = outb + ((size_t)tile * nco + cb * 4 + n * 2) * plane * 64;                        // wave-uniform
+        const unsigned lane_off = (unsigned)(((size_t)(q >> 2) * plane + (size_t)y_lane * a.W + x_lane) * 64 + (q & 3) * 16);
+        const int oyl = oy0 + y_lane, oxl = ox0 + x_lane;
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            if (it < it0 || it >= it1) continue;
+            const int zc = it >> 1, yc = (it & 1) * (32 / TX);
+            const int ozc = oz0 + zc, oy = oyl + yc;
+            if (!(OAI_EXP & 1) && cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
+                const unsigned uni = (unsigned)(((ozc * a.H + oy0 + yc) * a.W + ox0) * 64);                  // wave-uniform
+                float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
+                const float4 val = *reinterpret_cast<const float4*>(xb + (it * 256 + gtid) * 16);
+                if constexpr ((OAI_EXP & 32) != 0) *dstp = val;
+                else {
+                    __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                    __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                }
+                if constexpr ((OAI_EXP & 16) != 0) {
+                    asm volatile("" ::: "memory");
+                    __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                    __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
+                }
+            }
+        }
+    };
+    auto store_box = [&](int (&clo)[3], int (&chi)[3]) __attribute__((always_inline)) {      // what the copy-out writes: the tile's box cut down to what the consumer reads
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { clo[i] = blo[i]; chi[i] = bhi[i]; }
+        if (a.store_boxes) {
+            const int* sb = a.store_boxes + 6 * tile;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { clo[i] = max(clo[i], sb[i] - a.store_grow); chi[i] = min(chi[i], sb[3 + i] + a.store_grow); }
+        }
+    };
     if (stager) {
         // WS, waves 4-7: while the multipliers run the taps of chunk ch, transform the rows of chunk ch + 1 (requested a chunk ago: the wait is
         // short) into the other T buffer, then request chunk ch + 2 into the same rows; one barrier per chunk, the multipliers' chunk-end one
@@ -731,7 +775,15 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        for (int i = 0; i < 4 * NREP; ++i) __syncthreads();          // the barriers of the multipliers' epilogue
+        // the multipliers' epilogue: its four barriers per cout half, then this wave's half of the image's copy-out (the next half's first barrier
+        // waits for these LDS reads before the exchange overwrites the image)
+        int sclo[3], schi[3];
+        store_box(sclo, schi);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            for (int i = 0; i < 4; ++i) __syncthreads();
+            copy_out(n, EIT / 2, EIT, sclo, schi);
+        }
         return;
     }
     if constexpr (MS == 1) {
@@ -749,11 +801,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     OAI_WSTAMP(2);
     // ---- epilogue
     const unsigned seen = census_peek(a.census);                    // (waited for under the epilogue)
-    constexpr int TV = TZ * TY * TX;                                // 256 voxels
-    constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
-    unsigned char* const xb = lds + grp * XB;                       // exchange buffer, then output image, of this group
-    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
-    const int nco = (a.Cout + 15) / 16;
     float vmax = 0.0f;
     bool nonfinite = false;                                         // an output inside the box that is inf / NaN (an overflowed t): fmaxf would drop the NaN silently
     unsigned umax = 0;                                              // (MS = 1: the same as the largest |v| BIT PATTERN inside the box -- NaN > inf > every finite value as unsigned)
@@ -770,13 +817,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             asm volatile("" : "+v"(scv[n][q]), "+v"(shv[n][q]));
         }
     int clo[3], chi[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { clo[i] = blo[i]; chi[i] = bhi[i]; }
-    if (a.store_boxes) {
-        const int* sb = a.store_boxes + 6 * tile;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { clo[i] = max(clo[i], sb[i] - a.store_grow); chi[i] = min(chi[i], sb[3 + i] + a.store_grow); }
-    }
+    store_box(clo, chi);
     // wave F (= frequency F during the taps) finishes z slice F
     auto finish = [&](auto ftag) __attribute__((always_inline)) {
         constexpr int F = decltype(ftag)::value;
@@ -866,34 +907,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
             __syncthreads();
             OAI_WEP(1);
-            {
-                const int t5 = gtid >> 3, q = gtid & 7;
-                const int x_lane = t5 % TX, y_lane = t5 / TX;
-                const bool cok = cb * 4 + n * 2 + (q >> 2) < nco;
-                unsigned char* ob = outb + ((size_t)tile * nco + cb * 4 + n * 2) * plane * 64;                        // wave-uniform
-                const unsigned lane_off = (unsigned)(((size_t)(q >> 2) * plane + (size_t)y_lane * a.W + x_lane) * 64 + (q & 3) * 16);
-                const int oyl = oy0 + y_lane, oxl = ox0 + x_lane;
-#pragma unroll
-                for (int it = 0; it < EIT; ++it) {
-                    const int zc = it >> 1, yc = (it & 1) * (32 / TX);
-                    const int ozc = oz0 + zc, oy = oyl + yc;
-                    if (!(OAI_EXP & 1) && cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
-                        const unsigned uni = (unsigned)(((ozc * a.H + oy0 + yc) * a.W + ox0) * 64);                  // wave-uniform
-                        float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
-                        const float4 val = *reinterpret_cast<const float4*>(xb + (it * 256 + gtid) * 16);
-                        if constexpr ((OAI_EXP & 32) != 0) *dstp = val;
-                        else {
-                            __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
-                            __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
-                        }
-                        if constexpr ((OAI_EXP & 16) != 0) {
-                            asm volatile("" ::: "memory");
-                            __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
-                            __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
-                        }
-                    }
-                }
-            }
+            copy_out(n, 0, WS ? EIT / 2 : EIT, clo, chi);            // (WS: the staging waves, idle since the last chunk, take the other half of the pieces)
             if constexpr (TY == 8 && NP == 4) if (a.pool_out && !(OAI_EXP & 2)) {       // (main shape only: the host asks for it where the box is whole blocks of it)
                 // MaxPool3d(2) fused (ec3 / ec5; networks.py:117,122), from the block's image: thread = (pooled voxel, 4 channels of one of the two
                 // 16-channel records); the pooled record keeps the (h0, h1) PAIR of the window's largest joined value -- the rule of
