@@ -259,6 +259,17 @@ int oai_stitch_blocks(const float* blocks_dev, int n_classes, int D, int H, int 
                       const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
                       float* maps_dev, void* stream);
 
+/* The same assemble, reading the blocks where an all_gather of per-rank tile ranges left them (the reference's
+ * counterpart is the Dask gather of per-task results, dask_processing.py:170-189): rank r computed the tiles
+ * [bounds_host[r], bounds_host[r + 1]) and its blocks sit in slots [r * slot_stride, r * slot_stride + its count) of blocks_dev --
+ * ragged ranges are padded to slot_stride blocks per rank by the collective (all_gather_into_tensor needs equal pieces), and this
+ * entry reads through the table instead of a compacting copy of 189 MB per volume.  bounds_host: n_ranges + 1 ascending tile
+ * indices, [0] = 0, [n_ranges] = the tile count; n_ranges <= 64. */
+int oai_stitch_blocks_ranged(const float* blocks_dev, int n_classes, int D, int H, int W,
+                             const int tile_zyx[3], const int overlap_zyx[3], const int crop_zyx[3],
+                             const int* bounds_host, int n_ranges, int slot_stride,
+                             float* maps_dev, void* stream);
+
 /* Partition.__call__ (image_transforms.py:395-455) as a standalone gather: tiles [tile_begin, tile_end) of the reference's
  * z-major order, tiles_dev[t - tile_begin][tz][ty][tx] = reflect-padded volume (pad lo = overlap; numpy.pad 'reflect').  For
  * callers that use Partition directly; oai_segment_tiles never materialises tiles. */

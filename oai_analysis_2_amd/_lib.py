@@ -83,6 +83,7 @@ SIGNATURES = {
     "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "oai_unet_volume_flops": (_D, [_P, _I, _I, _I, _I3, _I3, _I3, _I, _I]),
     "oai_stitch_blocks": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _I3, _P, _P]),
+    "oai_stitch_blocks_ranged": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _I3, _P, _I, _I, _P, _P]),
     "oai_unet_tile_flops": (_D, [_P, _I, _I, _I, _I3, _I]),
     "oai_unet_tile_flops_conv3": (_D, [_P, _I, _I, _I, _I3, _I]),
     "oai_unet_profile": (_I, [_P, _I]),

@@ -4,9 +4,20 @@ Replaces the reference's Dask task graph for this path (dask_processing.py:46-18
 segmenter and the ICON model inside every task (:77, :170) and moves pickled ITK images between workers.
 Here the engines are built once per process; volume i+1 is uploaded on a side stream (pinned host buffer,
 PCIe Gen5: 94 MB in ~1.5 ms) while volume i computes, and results are copied back asynchronously.
+
+Round 5: NO host memcpy on the launch thread.  A volume moves 94 MB pageable -> pinned before its upload and
+566 MB pinned -> pageable behind its download (five result tensors); on the thread that queues the kernels those copies
+(and the page faults of 566 MB of fresh memory per volume) kept the GPU waiting: 6.03 volumes/s streamed against 7.22 resident.
+Both now run on two worker threads (numpy / torch copies release the GIL), over double-buffered pinned staging on either side;
+the launch thread only queues work and collects finished results one volume later.
 """
 from __future__ import annotations
 
+import queue
+import threading
+import time
+from collections import deque
+from concurrent.futures import Future, ThreadPoolExecutor
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -15,76 +26,146 @@ import torch
 from .image import Image, as_image
 from .pipeline import VolumePipeline, VolumeResult
 
+_RESULT_NAMES = ("fc", "tc", "phi", "fc_atlas", "tc_atlas")
+
 
 class CohortRunner:
-    """Three things overlap per volume: the compute of volume i (main stream), the host staging + H2D of volume i+1 and the D2H
-    of volume i-1's results (copy stream, persistent pinned buffers).  The host never blocks before the next compute is queued."""
+    """Four things overlap per volume: the compute of volume i (main stream, launch thread), the host staging + H2D of volume i+1
+    (upload worker, copy stream), the D2H of volume i-1's results (copy stream) and the host copy of volume i-2's results out of
+    the pinned buffers into memory the caller owns (download worker).  The launch thread never copies and never waits for a copy
+    that is not at least one volume old.  ``stats`` accumulates what the workers moved (bytes, seconds) for bench.py."""
+
+    N_OUT_SETS = 2                 # pinned result sets: one being filled by the D2H of volume i-1 while the worker empties the other
 
     def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False):
         self.pipe = pipeline
         self.keep_on_device = keep_on_device
-        self.copy_stream = torch.cuda.Stream(device=pipeline.unet.device)
+        self.copy_stream = torch.cuda.Stream(device=pipeline.unet.device)      # uploads (and the lazy normalisation of the next volume)
+        # downloads on a stream of their own: the D2H of volume i is queued right behind its compute and waits for it (~140 ms); on the
+        # upload stream it would hold the H2D of volume i+2 back behind that wait (PCIe is full duplex: the two directions do not compete)
+        self.down_stream = torch.cuda.Stream(device=pipeline.unet.device)
         self._pin_in: List[Optional[torch.Tensor]] = [None, None]       # double-buffered pinned upload staging
         self._pin_ev: List[Optional[torch.cuda.Event]] = [None, None]  # H2D out of each staging buffer has finished
-        self._pin_out: dict = {}
+        self._pin_out: List[dict] = [dict() for _ in range(self.N_OUT_SETS)]
+        self._free_out: "queue.Queue[int]" = queue.Queue()
+        for k in range(self.N_OUT_SETS):
+            self._free_out.put(k)
+        self._up = ThreadPoolExecutor(max_workers=1, thread_name_prefix="oai-upload")
+        self._down = ThreadPoolExecutor(max_workers=1, thread_name_prefix="oai-download")
+        self._clone = ThreadPoolExecutor(max_workers=5, thread_name_prefix="oai-clone")      # a volume's five result tensors are copied out side by side (one core
+        #                                                                                      does ~5-10 GB/s into freshly faulted pages: 566 MB would take most of a volume's compute time)
+        self._lock = threading.Lock()
+        self.stats = {"stage_bytes": 0, "stage_s": 0.0, "clone_bytes": 0, "clone_s": 0.0, "launch_wait_s": 0.0}
 
-    def _upload(self, img: Image, slot: int) -> Tuple[torch.Tensor, torch.cuda.Event]:
-        src = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32))
-        buf = self._pin_in[slot]
-        if buf is None or buf.shape != src.shape:
-            buf = self._pin_in[slot] = torch.empty(src.shape, dtype=torch.float32).pin_memory()
-        if self._pin_ev[slot] is not None:
-            self._pin_ev[slot].synchronize()                              # the previous upload out of this buffer is done
-        buf.copy_(src)                                                    # host memcpy into page-locked memory (no re-pinning per volume)
-        with torch.cuda.stream(self.copy_stream):
-            dev = buf.to(self.pipe.unet.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
-        self._pin_ev[slot] = ev
-        return dev, ev
+    def close(self) -> None:
+        self._up.shutdown(wait=True)
+        self._down.shutdown(wait=True)
+        self._clone.shutdown(wait=True)
 
-    def _download(self, res: VolumeResult, done: torch.cuda.Event) -> Optional[VolumeResult]:
-        """D2H of one volume's results on the copy stream (after `done`), through reusable pinned buffers.  The fp16 range flag
-        of the volume rides along (4 bytes); None = it overflowed and the results must not be used."""
-        self.copy_stream.wait_event(done)
-        outs = []
-        with torch.cuda.stream(self.copy_stream):
-            names = ("fc", "tc", "phi", "fc_atlas", "tc_atlas") + (("overflow",) if res.overflow is not None else ())
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ---- upload side (worker thread) --------------------------------------------------------------------------------------------
+    def _upload(self, fetch: Callable[[], Image], slot: int) -> Tuple[torch.Tensor, torch.cuda.Event, Image]:
+        """Runs on the upload worker: fetch the image (a lazy sequence reads + normalises the file here), stage it in pinned memory,
+        queue the H2D on the copy stream.  Returns (device tensor, upload event, host image)."""
+        img = as_image(fetch())
+        dev_id = self.pipe.unet.device
+        with torch.cuda.device(dev_id):
+            src = torch.from_numpy(np.ascontiguousarray(img.array, dtype=np.float32))
+            buf = self._pin_in[slot]
+            if buf is None or buf.shape != src.shape:
+                buf = self._pin_in[slot] = torch.empty(src.shape, dtype=torch.float32).pin_memory()
+            if self._pin_ev[slot] is not None:
+                self._pin_ev[slot].synchronize()                          # the previous upload out of this buffer is done
+            t0 = time.perf_counter()
+            buf.copy_(src)                                                # host memcpy into page-locked memory (no re-pinning per volume)
+            dt = time.perf_counter() - t0
+            with torch.cuda.stream(self.copy_stream):
+                dev = buf.to(dev_id, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self._pin_ev[slot] = ev
+        with self._lock:
+            self.stats["stage_bytes"] += src.numel() * 4
+            self.stats["stage_s"] += dt
+        return dev, ev, img
+
+    # ---- download side ----------------------------------------------------------------------------------------------------------------
+    def _queue_d2h(self, res: VolumeResult, done: torch.cuda.Event) -> Tuple[int, torch.cuda.Event, tuple]:
+        """Launch thread: D2H of one volume's results on the download stream (after `done`) into a free pinned set.  Blocks only when both
+        sets are still being emptied (the download worker is more than a volume behind: back-pressure, not a steady-state wait)."""
+        t0 = time.perf_counter()
+        k = self._free_out.get()
+        self.stats["launch_wait_s"] += time.perf_counter() - t0
+        pins = self._pin_out[k]
+        self.down_stream.wait_event(done)
+        names = _RESULT_NAMES + (("overflow",) if res.overflow is not None else ())
+        with torch.cuda.stream(self.down_stream):
             for name in names:
                 t = getattr(res, name)
                 key = (name, tuple(t.shape), t.dtype)
-                if key not in self._pin_out:
-                    self._pin_out[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-                self._pin_out[key].copy_(t, non_blocking=True)
-                t.record_stream(self.copy_stream)
-                outs.append(self._pin_out[key])
-        self.copy_stream.synchronize()
-        if res.overflow is not None and int(outs[5][0]):
-            return None
-        return VolumeResult(*(o.clone() for o in outs[:5]), repeated_f32=res.repeated_f32)   # the pinned buffers are reused by the next volume
+                if key not in pins:
+                    pins[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                pins[key].copy_(t, non_blocking=True)
+                t.record_stream(self.down_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.down_stream)
+        return k, ev, tuple((name, tuple(getattr(res, name).shape), getattr(res, name).dtype) for name in names)
+
+    def _collect(self, k: int, ev: torch.cuda.Event, keys: tuple, repeated: bool) -> Optional[VolumeResult]:
+        """Download worker: wait for the D2H, copy the results out of the pinned set into memory the caller owns, free the set.  None = the
+        fp16 range flag of the volume (4 bytes, rides along) is raised: the results must not be used."""
+        try:
+            ev.synchronize()
+            pins = self._pin_out[k]
+            if len(keys) > 5 and int(pins[keys[5]][0]):
+                return None
+            t0 = time.perf_counter()
+            outs = list(self._clone.map(lambda key: torch.empty(pins[key].shape, dtype=pins[key].dtype).copy_(pins[key]), keys[:5]))
+            dt = time.perf_counter() - t0
+            with self._lock:
+                self.stats["clone_bytes"] += sum(o.numel() * o.element_size() for o in outs)
+                self.stats["clone_s"] += dt
+            return VolumeResult(*outs, repeated_f32=repeated)
+        finally:
+            self._free_out.put(k)                                          # (the pinned buffers are reused by a later volume)
+
+    def _download_async(self, res: VolumeResult, done: torch.cuda.Event) -> Future:
+        k, ev, keys = self._queue_d2h(res, done)
+        return self._down.submit(self._collect, k, ev, keys, res.repeated_f32)
 
     def _finish(self, pending) -> VolumeResult:
-        """Results of a queued volume; a volume whose fp16x3 segmentation left fp16's range is repeated in exact fp32 here
-        (the check is lazy -- at download time -- so the overlap of the normal case is kept; never silent)."""
-        i, res, done, dev, img = pending
+        """Results of a queued volume whose download was started a volume ago; a volume whose fp16x3 segmentation left fp16's range is
+        repeated in exact fp32 here (the check is lazy -- at download time -- so the overlap of the normal case is kept; never silent)."""
+        i, res, done, dev, img, fut = pending
         if self.keep_on_device:
             done.synchronize()
-            if res.overflow is not None and int(res.overflow.item()):
-                res = self.pipe.rerun_f32(dev, img)
-                torch.cuda.current_stream().synchronize()
+            if res.overflow is not None:
+                raised = bool(int(res.overflow.item()))
+                self.pipe.unet.note_volume_flag(raised)
+                if raised:
+                    res = self.pipe.rerun_f32(dev, img)
+                    torch.cuda.current_stream().synchronize()
             return res
-        out = self._download(res, done)
+        out = fut.result()
+        if res.overflow is not None:
+            self.pipe.unet.note_volume_flag(out is None)
         if out is None:
             res = self.pipe.rerun_f32(dev, img)
             done = torch.cuda.Event()
             done.record()
-            out = self._download(res, done)
+            out = self._download_async(res, done).result()
         return out
 
     def run(self, images: Sequence, rank: int = 0, world: int = 1, queue=None) -> Iterator[Tuple[int, VolumeResult]]:
         """Yield (index, result) for the volumes this worker processes, in its processing order.  ``queue`` (a
         ``parallel.VolumeQueue`` shared by all ranks) assigns volumes dynamically -- the worker claims one volume ahead, so that its
-        upload overlaps the current compute; without a queue the static split index % world == rank is used."""
+        upload overlaps the current compute; without a queue the static split index % world == rank is used.  Results are yielded
+        ONE volume behind their compute's queueing (their host copy runs on the download worker meanwhile)."""
         if queue is not None:
             order = iter(queue)
         else:
@@ -93,13 +174,12 @@ class CohortRunner:
         if cur is None:
             return
         # every image is fetched from ``images`` exactly ONCE (a lazy sequence -- dask_processing._Lazy -- reads and normalises the file
-        # in __getitem__) and travels with its upload: (device tensor, upload event, host image)
-        img = as_image(images[cur])
-        nxt = (*self._upload(img, 0), img)
-        pending = None                                                    # (index, device results, completion event, ...) of the previous volume
+        # in __getitem__), on the upload worker, and travels with its upload: (device tensor, upload event, host image)
+        nxt = self._up.submit(self._upload, lambda i=cur: images[i], 0)
+        waiting: deque = deque()                                          # volumes whose compute is queued: (index, res, done, dev, img, download future | None)
         k = 0
         while cur is not None:
-            dev, ev, img = nxt
+            dev, ev, img = nxt.result()
             torch.cuda.current_stream().wait_event(ev)
             dev.record_stream(torch.cuda.current_stream())                # allocated on the copy stream, read by the compute stream
             res = self.pipe.run(dev, img, check=False)                    # queued, not waited for; the range flag is read at download time
@@ -107,10 +187,13 @@ class CohortRunner:
             done.record()
             following = next(order, None)                                 # claimed now: its host staging + H2D run behind this volume's compute
             if following is not None:
-                img_next = as_image(images[following])
-                nxt = (*self._upload(img_next, (k + 1) & 1), img_next)
-            if pending is not None:
-                yield pending[0], self._finish(pending)
-            pending = (cur, res, done, dev, img)
+                nxt = self._up.submit(self._upload, lambda i=following: images[i], (k + 1) & 1)
+            fut = None if self.keep_on_device else self._download_async(res, done)      # D2H queued behind `done`; the host copy on the worker
+            waiting.append((cur, res, done, dev, img, fut))
+            while len(waiting) > 1:                                       # hand out what is at least one volume old
+                p = waiting.popleft()
+                yield p[0], self._finish(p)
             cur, k = following, k + 1
-        yield pending[0], self._finish(pending)
+        while waiting:
+            p = waiting.popleft()
+            yield p[0], self._finish(p)

@@ -37,6 +37,8 @@ struct Layer {
     size_t panel_wino_floats = 0;
     float4* panel_wino16 = nullptr;     // the same weights laid out for the 16x16x32 taps of conv3_wino_sres<..., M16> (pack_wino16_panel; Cout % 128 == 0 only)
     size_t panel_wino16_floats = 0;
+    float4* panel_m16 = nullptr;        // the fp16 panel laid out for the 16x16x32 tap pairs of conv3_igemm_sres<..., M16> (pack_conv3_m16_panel): same values as panel_bf[2]
+    size_t panel_m16_floats = 0;
     std::vector<float> wk_host;         // canonical [27][cin][cout] weights of the k3 layers (for re-packing)
     std::vector<float> scale_host, shift_host, plain_host;
     float* plain = nullptr;             // ec0: [27][cout]; dc0: [ncls][cin]
@@ -66,6 +68,11 @@ struct oai_unet {
                                         // bit 5: the same for the 64-cout layer (dc2) -- ALL its launch shapes (specialised main blocks and x strip, slice-split y strip:
                                         // wino_m16_64), so a voxel's bits do not depend on the shape that covers it; measured within noise of bit 4 alone (-0.2 %), not the default
     int opt_wino_layers = 0x3FFFF;      // option "winograd_layers": bit k = layer k may take the Winograd kernel (A/B of single layers)
+    int opt_m16 = 1;                    // option "m16": the direct split-resident kernel (conv3_igemm_sres: ec1 + fused ec0, ec2, dc1 + fused head, ...) on
+                                        // v_mfma_f32_16x16x32_f16 tap pairs (round 5; another summation order) for every layer that can never take the bit-identical
+                                        // 128-cout form conv3_igemm_sres2 -- i.e. Cout % 128 != 0 -- so that a layer runs ONE order whatever shapes cover it and
+                                        // option "wide" stays bit-preserving
+    int opt_m16_layers = 0x3FFFF;       // option "m16_layers": bit k = layer k may take the tap-pair form (A/B of single layers)
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
@@ -220,6 +227,51 @@ static std::vector<float> pack_conv3_panel_bf(const std::vector<float>& wk, int 
                                     o16[u * 8 + j] = b;
                                 }
                             }
+        }
+    return out;
+}
+
+// Tap of step j (0..13), lane half tsel, of conv3_igemm_sres<..., M16>: 27 taps = 13 pairs + 1 (see the kernel's header comment).  t = (dz * 3 + dy) * 3 + dx.
+static inline int m16_step_tap(int j, int tsel) {
+    if (j < 9) return 3 * j + tsel;                          // (q = j, dx 0) | (q, dx 1)
+    if (j < 12) return 3 * (3 * (j - 9) + tsel) + 2;         // (q, dx 2) | (q + 1, dx 2), q = 0, 3, 6
+    if (j == 12) return 3 * (2 + 3 * tsel) + 2;              // (2, dx 2) | (5, dx 2)
+    return 26;                                               // (8, dx 2) alone
+}
+
+// Panel of conv3_igemm_sres<..., M16> (v_mfma_f32_16x16x32_f16, K = a PAIR of taps x 16 channels): [cb][chunk of 16][step 14][X' | Y'][n2 4][lane] x 8 fp16.
+// Lane (column c = lane & 15, group g = lane >> 4) of tile n2 holds cout cb * 64 + n2 * 16 + c, channels 8 (g & 1) .. + 7 of tap m16_step_tap(j, g >> 1):
+// X' = the HIGH terms b0 of both taps, Y' = the LOW terms b1.  Step 13 (the 27th tap alone, A = [a0 | a1]): X' = [b0 | b0], Y' = [b1 | 0].  The values are
+// pack_conv3_panel_bf's fp16 terms (same scales, same split).  + 1 step of prefetch slack (the kernel requests one step past its last).
+static std::vector<float> pack_conv3_m16_panel(const std::vector<float>& wk, int C0, int C1, int Cout, const std::vector<float>& wscale, float src1_factor) {
+    const int Cin = C0 + C1, KC = 16;
+    const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+    const size_t units = ((size_t)ncb * (nch0 + nch1) * 14 + 1) * 2 * 4 * 64;          // 16-byte units
+    std::vector<float> out(units * 4, 0.0f);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out.data());
+    size_t u = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nch0 + nch1; ++ch) {
+            const bool first = ch < nch0;
+            const int Csrc = first ? C0 : C1, cofs = first ? 0 : C0, cl0 = (first ? ch : ch - nch0) * KC;
+            for (int j = 0; j < 14; ++j)
+                for (int kind = 0; kind < 2; ++kind)             // 0: X', 1: Y'
+                    for (int n2 = 0; n2 < 4; ++n2)
+                        for (int lane = 0; lane < 64; ++lane, ++u) {
+                            const int g = lane >> 4, tsel = g >> 1;
+                            if (j == 13 && kind == 1 && tsel == 1) continue;           // step 13: Y' = [b1 | 0]
+                            const int t = m16_step_tap(j, tsel), term = kind;
+                            const int co = cb * 64 + n2 * 16 + (lane & 15);
+                            if (co >= Cout) continue;
+                            for (int e = 0; e < 8; ++e) {
+                                const int cl = cl0 + 8 * (g & 1) + e;
+                                if (cl >= Csrc) continue;
+                                float r = wk[((size_t)t * Cin + cofs + cl) * Cout + co] * wscale[co] * (first ? 1.0f : src1_factor);
+                                uint16_t b = 0;
+                                for (int kk = 0; kk <= term; ++kk) { b = f32_to_f16_rne(r); r -= f16_to_f32(b); }
+                                o16[u * 8 + e] = b;
+                            }
+                        }
         }
     return out;
 }
@@ -420,6 +472,12 @@ static int pack_fp16_layer(oai_unet* h, int k) {
     L.panel_f16_floats = panel.size();
     L.rel1 = rel1;
     if (int rc = upload_into(h, panel, &L.panel_bf[2])) return rc;
+    if (L.kind != 2) {                                               // the same terms in the order of the 16x16x32 tap pairs (conv3_igemm_sres<..., M16>)
+        const std::vector<float> p16 = pack_conv3_m16_panel(L.wk_host, L.c0, L.c1, L.cout, L.ws, f1);
+        if (L.panel_m16 && p16.size() != L.panel_m16_floats) return set_error(OAI_ERR_ARG, "16x16x32 panel of layer %d changed size", k);
+        L.panel_m16_floats = p16.size();
+        if (int rc = upload_into(h, p16, &L.panel_m16)) return rc;
+    }
     return (h->opt_wino || L.panel_wino) ? pack_wino_layer(h, k) : OAI_OK;
 }
 
@@ -515,7 +573,9 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
     }
     if (wide) a.ncb = a.Cout / 128;
     const bool bf = KC == 8 && h->precision != OAI_PREC_F32;       // the split kernels use 2 z slices per block (4: split-resident)
-    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? sres_mrep : 2) : MREP);
+    // exact fp32: two z slices per block -- the registers of the other two hold the per-chunk partial sums of its two-level accumulation (conv3_igemm_f32)
+    constexpr int kF32Mrep = MREP > 2 ? 2 : MREP;
+    a.nbz = cdiv(box.hi[0] - box.lo[0], bf ? (h->sres ? sres_mrep : 2) : kF32Mrep);
     a.nby = cdiv(box.hi[1] - box.lo[1], WY * RY);
     a.nbx = cdiv(box.hi[2] - box.lo[2], WX * RX);
     unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
@@ -540,9 +600,14 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         // stream of a wave that has the SIMD to itself, scripts/stamp_phases.py)
         static const int one_wg = diag_env("OAI_ONE_WG", 0);
         bool done = false;
+        // the 16x16x32 tap pairs (option "m16"): a per-LAYER decision -- never for a layer that the bit-identical 128-cout form conv3_igemm_sres2 may
+        // take for some of its launches (that choice depends on the launch size) -- and every shape of the kernel has the variant
+        const bool m16 = h->opt_m16 && a.wpanel16 && !h->sres_ring && !h->b_lds && a.Cout % 128 != 0 && !one_wg;
+        if (m16) a.wpanel = a.wpanel16;
         if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
             if (a.first_w) {                                         // ec0 fused into ec1's halo staging (first_fusable guarantees mrep 4, no strips)
-                conv3_igemm_sres<4, RX, RY, WY, WX, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+                if (m16) conv3_igemm_sres<4, RX, RY, WY, WX, false, true, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+                else conv3_igemm_sres<4, RX, RY, WY, WX, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
                 done = true;
             }
         }
@@ -569,6 +634,8 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
         }
         if (done) { }
         else if (a.first_w) return set_error(OAI_ERR_ARG, "fused ec0 asked of a tile shape that has no such kernel");
+        else if (m16 && sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX, false, false, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
+        else if (m16) conv3_igemm_sres<2, RX, RY, WY, WX, false, false, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else if (sres_mrep == 4 && h->b_lds) conv3_igemm_sres<4, RX, RY, WY, WX, false, false, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
         else if (sres_mrep == 4) conv3_igemm_sres<4, RX, RY, WY, WX><<<grid, 256, one_wg ? 24 * 1024 : 0, st>>>(a, h->zero_rec);
         else if (h->sres_ring && !mrep_override) conv3_igemm_sres<2, RX, RY, WY, WX, true><<<grid, 256, 0, st>>>(a, h->zero_rec);
@@ -577,7 +644,7 @@ static int launch_conv3_shape(const oai_unet* h, ConvArgs a, const Box& box, int
     else if (KC == 8 && h->precision == OAI_PREC_BF16X3) conv3_igemm_bf16s<2, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     else if (KC == 8 && h->precision == OAI_PREC_BF16X6) conv3_igemm_bf16s<3, false, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     else if (KC == 8 && h->precision == OAI_PREC_FP16X3) conv3_igemm_bf16s<2, true, 2, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
-    else conv3_igemm_f32<MREP, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
+    else conv3_igemm_f32<kF32Mrep, KC, RX, RY, WY, WX><<<grid, 256, 0, st>>>(a);
     OAI_CHECK_LAUNCH();
     if (h->profile) {
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
@@ -638,6 +705,7 @@ static int fill_conv_args(const oai_unet* h, const Layer& L, const float* s0, co
     a.out = out; a.Cout = L.cout; a.scale = f16 ? L.scale_f16 : L.scale; a.shift = f16 ? L.shift_f16 : L.shift;
     a.census = h->sres && h->opt_census ? h->census + 16 * (int)(&L - h->L) : nullptr;
     a.wpanel = h->precision == OAI_PREC_F32 ? L.panel : L.panel_bf[h->precision == OAI_PREC_BF16X3 ? 0 : h->precision == OAI_PREC_BF16X6 ? 1 : 2];
+    a.wpanel16 = h->precision == OAI_PREC_FP16X3 && ((h->opt_m16_layers >> (int)(&L - h->L)) & 1) ? L.panel_m16 : nullptr;
     a.D = dims[0]; a.H = dims[1]; a.W = dims[2];
     a.ncb = (L.cout + 63) / 64;
     a.relu = 1;
@@ -1101,6 +1169,9 @@ __global__ void range_flag_from_state_kernel(const int* __restrict__ state, int*
 
 using namespace oai;
 
+static int stitch_impl(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],
+                       const int crop[3], float* maps, void* stream, const StitchRanges& rg);
+
 extern "C" {
 
 int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn_eps, oai_unet** out) {
@@ -1252,6 +1323,12 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "winograd_layers")) {
         OAI_CHECK_ARG(value >= 0 && value <= 0x3FFFF, "oai_unet_set_option: winograd_layers is a mask over the 18 layers");
         h->opt_wino_layers = value;
+    } else if (!strcmp(name, "m16")) {                 // the direct kernel's taps on v_mfma_f32_16x16x32_f16 tap pairs (another summation order; default 1)
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: m16 must be 0 or 1");
+        h->opt_m16 = value;
+    } else if (!strcmp(name, "m16_layers")) {
+        OAI_CHECK_ARG(value >= 0 && value <= 0x3FFFF, "oai_unet_set_option: m16_layers is a mask over the 18 layers");
+        h->opt_m16_layers = value;
     } else if (!strcmp(name, "dead_stores")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: dead_stores must be 0 or 1");
         h->opt_dead_stores = value;
@@ -1675,6 +1752,35 @@ int oai_unet_tile_costs(const oai_unet* h, int D, int H, int W, const int tile[3
 
 int oai_stitch_blocks(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],
                       const int crop[3], float* maps, void* stream) {
+    StitchRanges rg{};
+    return stitch_impl(blocks, ncls, D, H, W, tile, overlap, crop, maps, stream, rg);
+}
+
+int oai_stitch_blocks_ranged(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],
+                             const int crop[3], const int* bounds_host, int n_ranges, int slot_stride, float* maps, void* stream) {
+    OAI_CHECK_ARG(bounds_host, "oai_stitch_blocks_ranged: null pointer");
+    OAI_CHECK_ARG(n_ranges >= 1 && n_ranges <= 64, "oai_stitch_blocks_ranged: 1..64 ranges, got %d", n_ranges);
+    StitchRanges rg{};
+    rg.n = n_ranges; rg.stride = slot_stride;
+    OAI_CHECK_ARG(bounds_host[0] == 0, "oai_stitch_blocks_ranged: the ranges must start at tile 0");
+    for (int r = 0; r <= n_ranges; ++r) {
+        rg.bound[r] = bounds_host[r];
+        if (r) OAI_CHECK_ARG(bounds_host[r] >= bounds_host[r - 1] && bounds_host[r] - bounds_host[r - 1] <= slot_stride,
+                             "oai_stitch_blocks_ranged: range %d is not ascending or longer than the slot stride %d", r - 1, slot_stride);
+    }
+    if (tile && overlap) {
+        long long nt = 1;
+        const int size[3] = {D, H, W};
+        for (int i = 0; i < 3; ++i) { const int e = tile[i] - 2 * overlap[i]; if (e > 0) nt *= (size[i] + e - 1) / e; }
+        OAI_CHECK_ARG(bounds_host[n_ranges] == nt, "oai_stitch_blocks_ranged: the ranges cover %d tiles, the volume has %lld", bounds_host[n_ranges], nt);
+    }
+    return stitch_impl(blocks, ncls, D, H, W, tile, overlap, crop, maps, stream, rg);
+}
+
+}  // extern "C"
+
+static int stitch_impl(const float* blocks, int ncls, int D, int H, int W, const int tile[3], const int overlap[3],
+                       const int crop[3], float* maps, void* stream, const StitchRanges& rg) {
     OAI_CHECK_ARG(blocks && maps && tile && overlap, "oai_stitch_blocks: null pointer");
     int eff[3], grid[3];
     const int size[3] = {D, H, W};
@@ -1693,9 +1799,7 @@ int oai_stitch_blocks(const float* blocks, int ncls, int D, int H, int W, const 
     size_t nblk = (total + 255) / 256;
     if (nblk > 256 * 32) nblk = 256 * 32;
     stitch_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(blocks, ncls, D, H, W, eff[0], eff[1], eff[2], grid[1], grid[2],
-                                                                crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, maps);
+                                                                crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, maps, rg);
     OAI_CHECK_LAUNCH();
     return OAI_OK;
 }
-
-}  // extern "C"

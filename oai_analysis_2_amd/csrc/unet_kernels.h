@@ -68,6 +68,7 @@ struct ConvArgs {
     int C0, C1;
     float* out; int Cout;
     const float4* wpanel;                    // packed weights (see pack_conv3_panel)
+    const float4* wpanel16 = nullptr;        // fp16x3: the same weights in the order of conv3_igemm_sres<..., M16>'s tap pairs (pack_conv3_m16_panel), or null
     const float* scale; const float* shift;  // per-cout epilogue: relu(acc*scale + shift)
     int D, H, W;                             // spatial dims of this level (per tile)
     int lo[3], hi[3];                        // output box to compute, [lo,hi) in z,y,x
@@ -188,13 +189,21 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
     if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + kConvTY <= blo[1] || ox0 >= bhi[2] || ox0 + kConvTX <= blo[2]) return;
     const int m_lo = max(0, blo[0] - oz0), m_hi = min(MREP, bhi[0] - oz0);   // z slices of this block that are needed
 
-    f32x16 acc[MREP][NREP];
+    // Two-level accumulation (round 5): v_mfma_f32_32x32x2_f32 adds TWO products per instruction into its fp32
+    // accumulator, so one running sum over K = 27 Cin is a chain of up to 10 368 roundings (dc8) -- measured 2.9-3.5 x as far from the
+    // reference network's float64 run as the reference's own fp32 run is, worse than the fp16x3 path (1.7-2.0 x: its MFMA sums 16 / 32
+    // products inside the instruction).  Here the MFMAs of one chunk (27 taps x KC channels = 108 instructions at KC 8) run into a FRESH
+    // accumulator set `part`, which is folded into the running sum `acc` by one fp32 add per element at the chunk end: a chain of 108 +
+    // Cin / 8 roundings instead of 27 Cin / 2 (dc8: 204 instead of 10 368).  The second set costs MREP x NREP x 16 registers, which is
+    // why the exact-fp32 path now runs two z slices per block (MREP 2: 64 + 64 accumulator registers, the 128 of the MREP 4 form; the
+    // weight fragments per MFMA double, at 1/16 of the fp16 kernels' MFMA rate that is nothing).
+    f32x16 acc[MREP][NREP], part[MREP][NREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
 #pragma unroll
         for (int n = 0; n < NREP; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.0f; part[m][n][r] = 0.0f; }
 
     const int row = lane & 31, half = lane >> 5;
     const int wy = wave / WX, wx = wave % WX;
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) {
                             const float bv = s == 0 ? bcur[n].x : s == 1 ? bcur[n].y : s == 2 ? bcur[n].z : bcur[n].w;
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
+                            part[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, part[m][n], 0, 0, 0);
                         }
                     }
                 }
@@ -283,6 +292,13 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < NREP; ++n) bcur[n] = bnext[n];
         }
+        // fold the chunk's partial sums into the running sums (one rounding per element and chunk)
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[m][n][r] += part[m][n][r]; part[m][n][r] = 0.0f; }
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -904,10 +920,21 @@ __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ in,
     }
 }
 
+// Where the block of tile t lives in a buffer that an all_gather of per-rank tile ranges left behind (oai_stitch_blocks_ranged): rank r's
+// range [bound[r], bound[r + 1]) sits in slots [r * stride, r * stride + its length) -- ragged ranges are padded to `stride` blocks per rank
+// by the collective, and the stitch reads through this table instead of a compacting copy.  n == 0: slot = tile (one contiguous list).
+struct StitchRanges { int n, stride; int bound[65]; };
+__device__ __forceinline__ size_t stitch_slot(const StitchRanges& rg, size_t t) {
+    if (rg.n == 0) return t;
+    int r = 0;
+    while (r + 1 < rg.n && (int)t >= rg.bound[r + 1]) ++r;
+    return (size_t)r * rg.stride + (t - (size_t)rg.bound[r]);
+}
+
 // Partition.assemble: blocks of all tiles -> maps[class][D][H][W] with trim + zeroed frame
 __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ blocks, int ncls, int D, int H, int W,
                                                      int ez, int ey, int ex, int gy, int gx, int cz, int cy, int cx,
-                                                     float* __restrict__ maps) {
+                                                     float* __restrict__ maps, const StitchRanges rg) {
     const size_t plane = (size_t)D * H * W;
     const size_t bvox = (size_t)ez * ey * ex;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane * ncls; i += (size_t)gridDim.x * 256) {
@@ -919,7 +946,7 @@ __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ b
                            (cx > 0 && (x < cx || x >= W - cx));
         if (!frame) {
             const int ti = z / ez, tj = y / ey, tk = x / ex;
-            const size_t t = ((size_t)ti * gy + tj) * gx + tk;
+            const size_t t = stitch_slot(rg, ((size_t)ti * gy + tj) * gx + tk);
             r = blocks[(t * ncls + k) * bvox + ((size_t)(z - ti * ez) * ey + (y - tj * ey)) * ex + (x - tk * ex)];
         }
         maps[i] = r;

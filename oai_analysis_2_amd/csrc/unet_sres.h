@@ -151,6 +151,16 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
     }
 }
 
+typedef float f32x4m __attribute__((ext_vector_type(4)));         // a native vector: inline asm can tie it to a 128-bit VGPR tuple (= f32x4 of unet_sres2.h)
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+// 16 bytes per lane from wave-uniform base (SGPR pair) + per-lane 32-bit offset + immediate, from inline assembly (= gload16_asm of unet_sres2.h)
+template <int IMM>
+__device__ __forceinline__ f32x4m gload16m(const void* sbase, unsigned voff) {
+    f32x4m v;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+    return v;
+}
+
 // ---- conv3, split-resident ---------------------------------------------------------------------------------------------
 // Same decomposition as conv3_igemm_bf16s (4 waves, 2 z slices per block, two workgroups per CU so that one computes
 // while the other stages), but the halo arrives by LDS-DMA: no staging registers, no staging VALU.
@@ -170,10 +180,27 @@ __global__ void __launch_bounds__(256) f32_to_sres_kernel(const float* __restric
 // fetch all of it through the CU's L1, in order behind the halo misses and the partner's stores -- go through a three-slot LDS ring:
 // every wave LDS-DMAs one KiB of the slab two taps ahead, one s_barrier per tap publishes it, and the fragments are read from LDS one tap
 // ahead.  12 KB on top of the 68 KB halo box: two workgroups fill the CU's 160 KB exactly.
-template <int MREP, int RX, int RY, int WY, int WX, bool RING = false, bool FIRST = false, bool BLDS = false>
+// M16 (round 5): the taps on v_mfma_f32_16x16x32_f16 instead of 32x32x16 -- what conv3_wino_sres<..., M16> (unet_wino.h) did for the two-group
+// Winograd form, for the DIRECT kernel (ec1 with the fused ec0, ec2, dc1 with the fused head, and every layer with option winograd 0).  This
+// loop runs at the power wall (1.72-1.74 GHz, profiles/r04_sq_summary.md); at equal cycles per FLOP the 16x16x32 shape holds a ~12-14 % higher
+// clock on split-fp16 data.  K = 32 = a PAIR OF TAPS x 16 channels, lanes 0-31 carrying the first tap of the pair, lanes 32-63 the second, so
+// that every A operand is a natural record read and every B operand a natural panel load (pack_conv3_m16_panel).  27 taps = 13 pairs + 1:
+//     steps 0..8   taps (q, dx 0) | (q, dx 1)                 q = dz * 3 + dy
+//     steps 9..11  taps (q, dx 2) | (q + 1, dx 2)             q = 0, 3, 6
+//     step  12     taps (2, dx 2) | (5, dx 2)
+//     step  13     tap (8, dx 2) alone: lanes 32-63 carry its LOW terms -- [a0 | a1] . [b0 | b0] = a0.b0 + a1.b0 and [a0 | a1] . [b1 | 0] = a0.b1
+// (pairs along dx first: the second tap of a pair is then ONE record further in x, or one row / one slice further for the dx = 2 taps -- seven
+// per-lane offsets cover all 14 steps).  Per step: pass B [a0 | a0'] . Y' (Y' = the low terms b1 of both taps), pass A [a0 | a0'] . X' (X' = the
+// high terms b0), pass C [a1 | a1'] . X'; Y' is dead after pass B and re-requested there, X' in halves behind pass C (32 fragment registers,
+// asm loads with counted waits -- the scheme of conv3_wino_sres<1, .., WS, M16>).  = 14 K-32 steps per chunk where 13.5 would be exact.  A wave's
+// tile is the same MREP x 32 rows x 64 couts as MREP x 2 tiles of 32 x 32 = MREP x 8 tiles of 16 x 16 (the same accumulator registers): element
+// (p, q, i) of the old (m, n) tile at row 16 p + 4 (lane >> 4) + i, cout column 16 q + (lane & 15).  Another summation order than the 32x32x16
+// form's (two taps at once), same arithmetic class; EVERY shape of this kernel has the variant, so a layer runs one order whatever shapes cover it.
+template <int MREP, int RX, int RY, int WY, int WX, bool RING = false, bool FIRST = false, bool BLDS = false, bool M16 = false>
 __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     static_assert(RX * RY == 32 && WY * WX == 4 && (MREP == 2 || MREP == 4) && (!RING || MREP == 2) && (!FIRST || !RING), "bad tile shape");
     static_assert(!BLDS || (MREP == 4 && !RING && !FIRST), "the weight ring is for the default kernel");
+    static_assert(!M16 || (!RING && !BLDS), "the 16x16x32 taps: the plain and the ec0-fused form");
     constexpr int NREP = 2, TZ = MREP;
     constexpr int kTY = WY * RY, kTX = WX * RX, HY = kTY + 2, HX = kTX + 2, HZ = TZ + 2;
     constexpr int HVOX = HZ * HY * HX;
@@ -229,13 +256,29 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 #define OAI_STAMP(i) do { } while (0)
 #define OAI_STAMPB(i) do { } while (0)
 #endif
-    f32x16 acc[MREP][NREP];
+    f32x16 acc[M16 ? 1 : MREP][M16 ? 1 : NREP];
+    f32x4m acc4[M16 ? MREP : 1][M16 ? NREP : 1][4];                   // M16: [m][n][p * 2 + q], element i at row 16 p + 4 (lane >> 4) + i, column 16 q + (lane & 15)
 #pragma unroll
-    for (int m = 0; m < MREP; ++m)
+    for (int m = 0; m < (M16 ? 1 : MREP); ++m)
 #pragma unroll
-        for (int n = 0; n < NREP; ++n)
+        for (int n = 0; n < (M16 ? 1 : NREP); ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < (M16 ? MREP : 1); ++m)
+#pragma unroll
+        for (int n = 0; n < (M16 ? NREP : 1); ++n)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc4[m][n][t] = f32x4m{0.0f, 0.0f, 0.0f, 0.0f};
+    // element r (0..15) of the (m, n) tile, whichever shape holds it, and its C/D row (voxel index inside the wave's 32-row tile)
+    auto acc_el = [&](int m, int n, int r) __attribute__((always_inline)) -> float {
+        if constexpr (M16) return acc4[m][n][r >> 2][r & 3];
+        else return acc[m][n][r];
+    };
+    const int col16 = lane & 15, rq16 = lane >> 4;                    // M16: this lane's cout column inside a 16-column tile, its row quarter
+    auto row_of = [&](int r) __attribute__((always_inline)) -> int {
+        return M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    };
 
     const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
     const size_t plane = (size_t)a.D * a.H * a.W;
@@ -461,7 +504,25 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 #pragma unroll
             for (int n = 0; n < NREP; ++n) dst[k][n] = *reinterpret_cast<const float4*>(blds + slot * 4096 + ((k * NREP + n) * 64 + lane) * 16);
     };
-    if constexpr (BLDS) {
+    // M16: the panel of pack_conv3_m16_panel, [cb][chunk][step 14][X' | Y'][n2 4][lane] x 16 B = 8 KiB per step; a wave-uniform base forced into an
+    // SGPR pair + this lane's 16 bytes, loaded by gload16_asm (invisible to the compiler's wait counting: every use goes through m16_wait first)
+    constexpr int STEP16 = 2 * 4 * 64 * 16;                         // bytes per step
+    const size_t wp16_v = (size_t)a.wpanel + (size_t)cb * nchunks * 14 * STEP16;
+    const unsigned char* wp16 = reinterpret_cast<const unsigned char*>(
+        ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wp16_v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp16_v));
+    const unsigned wlane = lane * 16;
+    f32x4m bXlo[2], bXhi[2], bY[4];                                 // X' (the high terms b0), couts n2 0, 1 and n2 2, 3, and Y' (the low terms b1) of the running step
+    auto m16_req_y = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16m<0>(wp16 + 4096, wlane) : n == 1 ? gload16m<1024>(wp16 + 4096, wlane) : n == 2 ? gload16m<2048>(wp16 + 4096, wlane) : gload16m<3072>(wp16 + 4096, wlane);      // (the immediate is 13 bits, signed)
+    };
+    auto m16_req_lo = [&]() __attribute__((always_inline)) { bXlo[0] = gload16m<0>(wp16, wlane); bXlo[1] = gload16m<1024>(wp16, wlane); };
+    auto m16_req_hi = [&]() __attribute__((always_inline)) { bXhi[0] = gload16m<2048>(wp16, wlane); bXhi[1] = gload16m<3072>(wp16, wlane); };
+    if constexpr (M16) {
+        // (no request here: the fragments of a chunk's step 0 are requested at the chunk's top, see run_chunks -- an asm load must never be in
+        // flight across a control-flow merge: the compiler believes its result register already holds the value and may COPY it on an edge)
+        asm volatile("s_nop 4" : "+s"(wp16) :: "memory");          // wp16 has just been made uniform by v_readfirstlane: five wait states before a VMEM reads it
+    } else if constexpr (BLDS) {
         issue_b(0); issue_b(1); issue_b(2);
     } else {
 #pragma unroll
@@ -552,13 +613,141 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 OAI_STAMP(1);
+                if constexpr (M16) {
+                    // the weight fragments of this chunk's step 0, requested in front of the halo staging: they land under the same wait.  They
+                    // are NOT requested during the previous chunk's last step: an inline-asm load is invisible to the compiler -- it believes
+                    // the result register holds the value from the asm statement on -- so a load in flight across the loop's back edge, the
+                    // dispatch over the live-slice variants or the loop exit can be COPIED (register re-assignment on an edge) or its register
+                    // re-used before the data has arrived.  Found with blocks of 1 and 3 live slices: their loop pre-headers copied the
+                    // prologue's in-flight fragments (v_mov of stale registers), intermittently wrong results at small tile levels.  Every asm
+                    // load of this kernel is now requested AND waited for inside one basic block.
+                    if constexpr (!FIRST) { m16_req_y(); m16_req_lo(); m16_req_hi(); }
+                }
                 if constexpr (FIRST) { if (!OAI_DBG_BIT(a, 4)) stage_first(ch); }
                 else if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
+                if constexpr (M16 && FIRST) { m16_req_y(); m16_req_lo(); m16_req_hi(); }      // (behind ec0's arithmetic, which has branches: same basic block as the wait below)
                 OAI_STAMP(2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
                 OAI_STAMP(3);
                 __syncthreads();                                             // ... and everybody else's
                 OAI_STAMP(4);
+                if constexpr (M16) {
+                    // ---- 14 steps of tap pairs on v_mfma_f32_16x16x32_f16 (see the kernel's header comment).  Vector-memory order per step:
+                    // Y'(j+1) behind pass B | X' lo(j+1) behind pass C lo | X' hi(j+1) behind pass C hi; the counted waits leave exactly the
+                    // younger requests in flight.  (The fragments of this chunk's step 0 were requested during the previous chunk's last step
+                    // -- or in the prologue -- and have landed behind the staging wait above: vmcnt(0) is global.)
+                    constexpr int SLB = HY * HX * 64;                           // bytes between the z slices of the halo box
+                    constexpr int POFF = (RX >= 32 ? 16 : (16 / RX) * HX) * 64;  // ... between rows 0-15 and rows 16-31 of the wave's tile
+                    auto tapc = [](int q) constexpr { return ((q / 3) * HY + q % 3) * HX * 64; };      // tap (dz, dy) = q, dx 0
+                    // this lane's record slot per step: lane group g = lane >> 4 reads channel half g & 1 of the pair's tap g >> 1
+                    int lq = lane;
+                    asm volatile("" : "+v"(lq));                                 // (recomputed every chunk: not held -- or spilled -- across the staging)
+                    const int r16 = lq & 15, hsel = (lq >> 4) & 1, tsel = lq >> 5;
+                    const int lx0 = wx * RX + r16 % RX, ly0 = wy * RY + r16 / RX;
+                    const unsigned vbase = (unsigned)((ly0 * HX + lx0) * 64);
+                    unsigned oA[2], oB[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        oA[k] = vbase + (unsigned)(tsel * 64 + (((k * 2 + hsel) ^ (((lx0 + tsel) >> 2) & 3)) << 4));       // steps 0..8: dx = tsel
+                        oB[k] = vbase + (unsigned)(128 + (((k * 2 + hsel) ^ (((lx0 + 2) >> 2) & 3)) << 4));                // steps 9..12: dx = 2
+                    }
+                    const unsigned oC = vbase + (unsigned)(128 + (((tsel * 2 + hsel) ^ (((lx0 + 2) >> 2) & 3)) << 4));     // step 13: term = tsel
+                    const unsigned tHX = (unsigned)(tsel * HX * 64);             // the second tap of a dx = 2 pair: one row (steps 9..11) / one slice (step 12) further
+                    auto a_off = [&](int j, int k) __attribute__((always_inline)) -> unsigned {
+                        if (j < 9) return oA[k] + (unsigned)tapc(j);
+                        if (j < 12) return oB[k] + tHX + (unsigned)tapc(3 * (j - 9));
+                        if (j == 12) return oB[k] + tHX * (unsigned)HY + (unsigned)tapc(2);
+                        return oC + (unsigned)tapc(8);
+                    };
+                    auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
+                        return *reinterpret_cast<const float4*>(lds + off + m * SLB + p * POFF);
+                    };
+                    auto mma = [&](const float4& av, const f32x4m& bv, f32x4m& c) __attribute__((always_inline)) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m, av), __builtin_bit_cast(f16x8m, bv), c, 0, 0, 0);
+                    };
+                    // the staging wait was vmcnt(0): the fragments of step 0 are in their registers (tie them behind it)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bY[0]), "+v"(bY[1]), "+v"(bY[2]), "+v"(bY[3]) :: "memory");
+                    asm volatile("" : "+v"(bXlo[0]), "+v"(bXlo[1]), "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                    float4 af[MREP][2];                                          // [m][p]: the A fragments of the running pass
+#pragma unroll
+                    for (int m = 0; m < ML; ++m)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) af[m][p] = lda(a_off(0, 0), m, p);
+                    // one step, J a compile-time constant: the 14 steps are 14 explicit calls (a `#pragma unroll` loop is a request -- hipcc left the
+                    // ML = 4 body rolled, with run-time tests of j, i.e. branches while fragment loads are in flight: tests/test_abi_cpu.py (g))
+                    auto m16_step = [&](auto jtag) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jtag)::value;
+                        if (j > 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bY[0]), "+v"(bY[1]), "+v"(bY[2]), "+v"(bY[3]) :: "memory");      // Y'(j) has landed; younger: lo(j), hi(j)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < ML; ++m)                              // pass B: a0 . Y'   (step 13: [a0 | a1] . [b1 | 0])
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 4; ++n) mma(af[m][p], bY[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        wp16 += STEP16;
+                        if (j < 13) m16_req_y();                                  // Y' of the next step (step 13 requests nothing: see the chunk's top)
+                        if (j > 0 && j < 13) asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");      // lo(j); younger: hi(j), Y'(j + 1)
+                        if (j == 13) asm volatile("s_waitcnt vmcnt(2)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");              // (step 13: only hi(13) is younger)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < ML; ++m)                              // pass A, low couts: a0 . X'[0, 1] over all slices
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
+                        __builtin_amdgcn_sched_barrier(0);                        // (the wait below must not rise above these MFMAs: they are its lead)
+                        if (j > 0 && j < 13) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");      // hi(j); younger: Y'(j + 1)
+                        if (j == 13) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");              // (step 13: nothing is younger)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < ML; ++m) {                            // pass A, high couts; behind each slice the a1 fragments of pass C take its registers
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (j < 13) {
+#pragma unroll
+                                for (int p = 0; p < 2; ++p) af[m][p] = lda(a_off(j, 1), m, p);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (j < 13) {
+#pragma unroll
+                            for (int m = 0; m < ML; ++m)                          // pass C, low couts: a1 . X'[0, 1]
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                    for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (j < 13) m16_req_lo();                                 // the low couts of the next step's X'
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j < 13) {
+#pragma unroll
+                            for (int m = 0; m < ML; ++m) {                        // pass C, high couts; behind each slice the a0 fragments of the next step
+#pragma unroll
+                                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                                    for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int p = 0; p < 2; ++p) af[m][p] = lda(a_off(j + 1, 0), m, p);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        if (j < 13) m16_req_hi();                                 // the high couts of the next step's X'
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    m16_step(std::integral_constant<int, 0>{}); m16_step(std::integral_constant<int, 1>{}); m16_step(std::integral_constant<int, 2>{});
+                    m16_step(std::integral_constant<int, 3>{}); m16_step(std::integral_constant<int, 4>{}); m16_step(std::integral_constant<int, 5>{});
+                    m16_step(std::integral_constant<int, 6>{}); m16_step(std::integral_constant<int, 7>{}); m16_step(std::integral_constant<int, 8>{});
+                    m16_step(std::integral_constant<int, 9>{}); m16_step(std::integral_constant<int, 10>{}); m16_step(std::integral_constant<int, 11>{});
+                    m16_step(std::integral_constant<int, 12>{}); m16_step(std::integral_constant<int, 13>{});
+                    OAI_STAMP(5);
+                } else {                                                     // (discarded for M16: its accumulators have another type)
                 if constexpr (BLDS) { if (ch == 0) read_b(bcur, 0); }           // slab 0 (landed with the halo, behind the barrier above)
                 load_a(acur[0], 0, 0);
 #pragma unroll
@@ -603,6 +792,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         for (int n = 0; n < NREP; ++n) bcur[k][n] = bnext[k][n];
                 }
                 OAI_STAMP(5);
+                }
             }
         };
         const int ml = m_lo == 0 ? m_hi : MREP;                         // workgroup-uniform
@@ -618,6 +808,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         }
     }
 
+    // (M16: nothing is in flight here -- step 13 requests nothing and waits for everything it uses)
     // ---- epilogue: relu(acc*scale + shift), split once, stored as format S.  The C/D layout gives a lane ONE channel of 16
     // voxels, i.e. 4-byte pieces of 64-byte records; stored directly that is 128 dword stores per wave with 64-bit address
     // arithmetic each (13% of the whole segmentation, profiles/r01_ablation.md).  Instead the block's output image is built in
@@ -642,14 +833,15 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         for (int k = 0; k < 4; ++k) hacc[j][k] = 0.0f;
     // this lane's column scales / shifts of both cout halves, loaded and WAITED FOR once, here: loaded inside the loop, the second half's
     // pair is waited for with vmcnt(0) behind the first half's copy-out stores, i.e. until those have reached memory
-    float scv[NREP], shv[NREP];
+    float scv[NREP][M16 ? 2 : 1], shv[NREP][M16 ? 2 : 1];            // M16: this lane's columns 16 q + (lane & 15), q = 0, 1, of the 32-cout half n
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-        const int co = cb * 64 + n * 32 + row;
-        scv[n] = co < a.Cout ? a.scale[co] : 0.0f; shv[n] = co < a.Cout ? a.shift[co] : 0.0f;
-    }
-    static_assert(NREP == 2, "the operand list below names both halves");
-    asm volatile("" : "+v"(scv[0]), "+v"(scv[1]), "+v"(shv[0]), "+v"(shv[1]));
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int q = 0; q < (M16 ? 2 : 1); ++q) {
+            const int co = cb * 64 + n * 32 + (M16 ? q * 16 + col16 : row);
+            scv[n][q] = co < a.Cout ? a.scale[co] : 0.0f; shv[n][q] = co < a.Cout ? a.shift[co] : 0.0f;
+            asm volatile("" : "+v"(scv[n][q]), "+v"(shv[n][q]));
+        }
     // what the copy-out writes: the tile's box, cut down to what the consumer of this tensor reads (ConvArgs::store_boxes)
     int clo[3], chi[3];
 #pragma unroll
@@ -667,7 +859,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         const unsigned ylen = (unsigned)(bhi[1] - blo[1]), xlen = (unsigned)(bhi[2] - blo[2]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int rr = row_of(r);
             const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
             okmask |= ((unsigned)(oy0 + ty - blo[1]) < ylen && (unsigned)(ox0 + tx - blo[2]) < xlen ? 1u : 0u) << r;
         }
@@ -675,13 +867,16 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
     const float relu_floor = a.relu ? 0.0f : -__builtin_inff();
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
-        const int co = cb * 64 + n * 32 + row;
-        const bool cvalid = co < nco * 16;                            // padded channels of the last chunk are written as 0
-        const float sc = scv[n], sh = shv[n];
-        const bool odd = row & 1;
+        const int co = cb * 64 + n * 32 + row;                        // (32x32 form: this lane's cout)
+        // padded channels of the last chunk are written as 0.  M16: a lane holds the columns 16 q + col16 of both records q of the half; nco * 16 is a
+        // multiple of 16, so record q is valid or not as a whole -- the record-1 test selects per element below
+        const bool cvalid = M16 ? cb * 64 + n * 32 < nco * 16 : co < nco * 16;
+        const bool cvalid1 = cb * 64 + n * 32 + 16 < nco * 16;        // M16: the half's second record
+        const bool odd = (M16 ? col16 : row) & 1;
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-        unsigned char* lrow = lds + (row >> 4) * 64 + ((row & 15) >> 1) * 4;
+        unsigned char* lrow = lds + (M16 ? 0 : (row >> 4) * 64) + (((M16 ? col16 : row) & 15) >> 1) * 4;
         unsigned omn = cvalid ? okmask : 0u;
+        if constexpr (M16) { if (!cvalid1) omn &= 0x0F0Fu; }          // elements r with (r >> 2) & 1 == 1 belong to record 1
         asm volatile("" : "+v"(omn));                                 // (per half: no compare masks carried from the first half to the second)
         __syncthreads();                                              // halo reads / the previous half's copy-out are done
         OAI_STAMPB(n == 0 ? 0 : 2);
@@ -694,11 +889,12 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
             for (int r = 0; r < 16; r += 2) {                          // C/D rows r, r+1 = x-adjacent voxels
                 float v[2];
                 int vox[2];
+                const float sc = scv[n][M16 ? (r >> 2) & 1 : 0], sh = shv[n][M16 ? (r >> 2) & 1 : 0];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int rr = ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * half;
+                    const int rr = row_of(r + e);
                     const int tx = wx * RX + rr % RX, ty = wy * RY + rr / RX;
-                    const float x = fmaxf(acc[m][n][r + e] * sc + sh, relu_floor);
+                    const float x = fmaxf(acc_el(m, n, r + e) * sc + sh, relu_floor);
                     // voxels outside the box are never copied out: 0 (bitwise AND with the sign-extended mask bit: v_bfe_i32, no compare, no SGPR mask)
                     v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (unsigned)__builtin_amdgcn_sbfe(om, r + e, 1));
                     vox[e] = (m * kTY + ty) * kTX + tx;
@@ -706,7 +902,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));  // fp16 range guard (checked once, below)
                 unsigned w_hi, w_lo;
                 split_two_voxels(v[0], v[1], sel, w_hi, w_lo);
-                unsigned char* dst = lrow + (odd ? vox[1] : vox[0]) * 128;
+                unsigned char* dst = lrow + (odd ? vox[1] : vox[0]) * 128 + (M16 ? ((r >> 2) & 1) * 64 : 0);      // (M16: record q = (r >> 2) & 1 of the half)
                 *reinterpret_cast<unsigned*>(dst) = w_hi;
                 *reinterpret_cast<unsigned*>(dst + 32) = w_lo;
             }
@@ -815,7 +1011,12 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 unsigned char* pb = reinterpret_cast<unsigned char*>(a.pool_out);
                 const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
                 const bool relu = a.relu != 0;
-                auto val = [&](int m, int r) { const float v = acc[m][n][r] * sc + sh; return relu ? fmaxf(v, 0.0f) : v; };
+                // a 2 x 2 x 2 window = elements r0, r0 + 1 (x pair), r0 + 8, r0 + 9 (the next y row) of slices m, m + 1 -- in both accumulator layouts.
+                // 32x32: g = the x group (rows 0..3 / 8..11), one cout per lane; M16: g = the 16-cout record q of the half, x from the row quarter
+                auto val = [&](int m, int r) {
+                    const float v = acc_el(m, n, r) * scv[n][M16 ? (r >> 2) & 1 : 0] + shv[n][M16 ? (r >> 2) & 1 : 0];
+                    return relu ? fmaxf(v, 0.0f) : v;
+                };
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -825,9 +1026,10 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         for (int m = 0; m < MREP; m += 2) {
                             float v = fmaxf(fmaxf(val(m, r0), val(m, r0 + 1)), fmaxf(val(m, r0 + 8), val(m, r0 + 9)));
                             v = fmaxf(v, fmaxf(fmaxf(val(m + 1, r0), val(m + 1, r0 + 1)), fmaxf(val(m + 1, r0 + 8), val(m + 1, r0 + 9))));
-                            const int x = ox0 + 8 * g + 4 * half + 2 * p, y = oy0 + 2 * wy, z = oz0 + m;
+                            const int x = M16 ? ox0 + 4 * rq16 + 2 * p : ox0 + 8 * g + 4 * half + 2 * p, y = oy0 + 2 * wy, z = oz0 + m;
+                            const int pco = M16 ? cb * 64 + n * 32 + 16 * g + col16 : co;
                             store_split_pair(pb + srec(tile, nco, (size_t)Dp * Hp * Wp, 0, (((size_t)(z / 2)) * Hp + y / 2) * Wp + x / 2), (size_t)Dp * Hp * Wp * 64,
-                                             co, v, cvalid, a.range_flag);
+                                             pco, v, M16 ? (g ? cvalid1 : cvalid) : cvalid, a.range_flag);
                         }
                     }
             }

@@ -797,7 +797,14 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         else run_chunks(std::integral_constant<int, 0>{});
     }
 
-    if constexpr (D > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // fragments requested past the last tap: never used, drained before their registers are reused
+    // fragments requested past the last tap / step: never used, but still in flight INTO their registers -- the wait names them, so that they stay
+    // allocated until it has executed (a bare wait lets the compiler reuse the "dead" registers between the loop exit and the wait: unet_sres.h)
+    if constexpr (WS && M16) {
+        if (!stager) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bY[0]), "+v"(bY[1]), "+v"(bY[2]), "+v"(bY[3]), "+v"(bXlo[0]), "+v"(bXlo[1]), "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+    } else if constexpr (D > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]), "+v"(bq[1][1][1]),
+                     "+v"(bq[NB - 1][0][0]), "+v"(bq[NB - 1][0][1]), "+v"(bq[NB - 1][1][0]), "+v"(bq[NB - 1][1][1]) :: "memory");
+    }
     OAI_WSTAMP(2);
     // ---- epilogue
     const unsigned seen = census_peek(a.census);                    // (waited for under the epilogue)

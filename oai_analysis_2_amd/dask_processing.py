@@ -126,7 +126,7 @@ def process_cohort(images: Sequence, atlas_image, worker: Optional[Worker] = Non
     if eng.precision == "fp16x3" and len(images):
         # ONE calibration for the cohort: the checkpoint's sidecar if there is one, else rank 0 calibrates on volume 0 (and writes the
         # sidecar); every rank takes rank 0's exponents, so a volume's maps do not depend on which rank the queue hands it to
-        eng.set_calibration_file(seg.calibration_file)
+        eng.set_calibration_file(seg.calibration_file, write=getattr(seg, "calibration_write", False))
 
         def _calibrate_on_first():
             vol0 = image_normalize(readimage(images[0]), 0.1, 99.9, 0, 1)

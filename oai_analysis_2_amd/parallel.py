@@ -46,45 +46,150 @@ def tile_range_for_rank(n_tiles: int, rank: int, world: int, costs: Optional[Seq
     return bounds[rank], bounds[rank + 1]
 
 
+# (name, kind, cin, cout, output level) of the reference UNet (networks.py:43-64); kind: 0 / 1 = k3 conv / transposed conv, 2 = k2s2 up-conv, 3 = 1x1x1 head
+_UNET_LAYERS = (("ec0", 0, 1, 32, 0), ("ec1", 0, 32, 64, 0), ("ec2", 0, 64, 64, 1), ("ec3", 0, 64, 128, 1), ("ec4", 0, 128, 128, 2),
+                ("ec5", 0, 128, 256, 2), ("ec6", 0, 256, 256, 3), ("ec7", 0, 256, 512, 3), ("dc9", 2, 512, 512, 2), ("dc8", 1, 768, 256, 2),
+                ("dc7", 1, 256, 256, 2), ("dc6", 2, 256, 256, 1), ("dc5", 1, 384, 128, 1), ("dc4", 1, 128, 128, 1), ("dc3", 2, 128, 128, 0),
+                ("dc2", 1, 192, 64, 0), ("dc1", 1, 64, 64, 0), ("dc0", 3, 64, 2, 0))
+
+
+def tile_costs_host(size_zyx: Sequence[int], tile_zyx: Sequence[int], overlap_zyx: Sequence[int], crop_zyx: Optional[Sequence[int]] = None,
+                    layers=_UNET_LAYERS) -> List[float]:
+    """FLOPs of every tile as ``oai_segment_tiles`` computes it -- the host mirror of ``oai_unet_tile_costs`` (csrc/unet.hip: keep_interval,
+    plan_regions, layer_flops) for planning a tile shard WITHOUT a device handle (a scheduler, bench.py --dry-run, the CPU tests; on a GPU box
+    ``UNetEngine.tile_costs`` is the same list, asserted in tests/test_fullsize_gpu.py).  Border tiles are cheaper: Partition.assemble zeroes a
+    frame of ``crop`` voxels and trims to the image (image_transforms.py:504-513), and every layer computes only the box its consumers need."""
+    size, tile, ovl = [int(v) for v in size_zyx], [int(v) for v in tile_zyx], [int(v) for v in overlap_zyx]
+    crop = [int(v) for v in crop_zyx] if crop_zyx is not None else [0, 0, 0]
+    eff = [t - 2 * o for t, o in zip(tile, ovl)]
+    grid = [-(-s // e) for s, e in zip(size, eff)]
+    dims = [[t >> l for t in tile] for l in range(4)]
+
+    def grow(b, lvl):
+        return ([max(0, a - 1) for a in b[0]], [min(f, h + 1) for h, f in zip(b[1], dims[lvl])])
+
+    def halve(b):
+        return ([a // 2 for a in b[0]], [(h + 1) // 2 for h in b[1]])
+
+    costs = []
+    for t in range(grid[0] * grid[1] * grid[2]):
+        idx = (t // (grid[1] * grid[2]), (t // grid[2]) % grid[1], t % grid[2])
+        lo = [ovl[i] + max(0, crop[i] - idx[i] * eff[i]) for i in range(3)]
+        hi = [ovl[i] + min(eff[i], size[i] - crop[i] - idx[i] * eff[i]) for i in range(3)]
+        if any(h <= l for l, h in zip(lo, hi)):
+            costs.append(0.0)
+            continue
+        need = {name: ([0, 0, 0], list(dims[lvl])) for name, _, _, _, lvl in layers}
+        need["dc0"] = need["dc1"] = (lo, hi)
+        need["dc2"] = grow(need["dc1"], 0)
+        need["dc3"] = grow(need["dc2"], 0)
+        need["dc4"] = halve(need["dc3"])
+        need["dc5"] = grow(need["dc4"], 1)
+        need["dc6"] = grow(need["dc5"], 1)
+        need["dc7"] = halve(need["dc6"])
+        need["dc8"] = grow(need["dc7"], 2)
+        f = 0.0
+        for name, kind, cin, cout, _ in layers:
+            b = need[name]
+            vox = float((b[1][0] - b[0][0]) * (b[1][1] - b[0][1]) * (b[1][2] - b[0][2]))
+            f += 2.0 * vox * (27 if kind in (0, 1) else 1) * cin * cout
+        costs.append(f)
+    return costs
+
+
 def volumes_for_rank(n_volumes: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_volumes, world))
 
 
-def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None, costs: Optional[Sequence[float]] = None) -> torch.Tensor:
-    """all_gather the per-rank centre blocks [n_local, C, ez, ey, ex] into [n_tiles, C, ez, ey, ex].
+class GatheredBlocks:
+    """What one all_gather of per-rank tile ranges leaves behind: ``buffer`` [world * stride, C, ez, ey, ex], rank r's blocks in slots
+    [r * stride, r * stride + (bounds[r + 1] - bounds[r])).  ``UNetEngine.stitch`` reads it through ``oai_stitch_blocks_ranged`` -- no
+    compacting copy; ``compact()`` is the plain [n_tiles, ...] tensor for callers that want one (a view when the ranges are equal)."""
 
-    Ranges are contiguous and ordered by rank, so concatenating the gathered pieces is the stitch order.
-    Uneven ranges (n_tiles % world != 0) are padded to the largest range for the collective.
-    """
+    def __init__(self, buffer: torch.Tensor, bounds: Sequence[int], stride: int):
+        self.buffer, self.bounds, self.stride = buffer, [int(v) for v in bounds], int(stride)
+
+    @property
+    def n_tiles(self) -> int:
+        return self.bounds[-1]
+
+    def slot(self, rank: int) -> torch.Tensor:
+        """The view of ``buffer`` that rank ``rank`` fills: [count_r, C, ez, ey, ex]."""
+        return self.buffer[rank * self.stride: rank * self.stride + self.bounds[rank + 1] - self.bounds[rank]]
+
+    def compact(self) -> torch.Tensor:
+        world = len(self.bounds) - 1
+        if all(self.bounds[r + 1] - self.bounds[r] == self.stride for r in range(world)):
+            return self.buffer
+        return torch.cat([self.slot(r) for r in range(world)], 0)
+
+
+def _tile_bounds(n_tiles: int, world: int, costs) -> List[int]:
+    ranges = [tile_range_for_rank(n_tiles, r, world, costs) for r in range(world)]
+    return [0] + [e for _, e in ranges]
+
+
+def gather_blocks_padded(local_blocks: torch.Tensor, n_tiles: int, group=None, costs: Optional[Sequence[float]] = None,
+                         into: Optional[GatheredBlocks] = None) -> GatheredBlocks:
+    """ONE all_gather of the per-rank centre blocks, without a pad + cat on the send side or a compacting cat behind it (VERDICT r4
+    #4b: 2 x 189 MB of copies per volume around a 189 MB collective): the gather buffer holds ``stride`` = the largest range's
+    blocks per rank, every rank's blocks go (or already are: ``into`` from ``alloc_gather``, ``local_blocks`` = its ``slot(rank)``)
+    in their slot, the collective runs IN PLACE on that buffer, and the stitch reads the ragged layout through a table."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bounds = _tile_bounds(n_tiles, world, costs)
+    stride = max(bounds[r + 1] - bounds[r] for r in range(world))
+    if bounds[rank + 1] - bounds[rank] != local_blocks.shape[0]:
+        raise ValueError("local block count does not match this rank's tile range")
+    g = into
+    if g is None:
+        g = GatheredBlocks(torch.empty((world * stride, *local_blocks.shape[1:]), dtype=local_blocks.dtype, device=local_blocks.device), bounds, stride)
+    elif g.bounds != bounds or g.stride != stride or g.buffer.shape[1:] != local_blocks.shape[1:]:
+        raise ValueError("gather buffer was allocated for another split")
+    mine = g.slot(rank)
+    if local_blocks.data_ptr() != mine.data_ptr() and local_blocks.shape[0]:
+        mine.copy_(local_blocks)                                   # (callers that computed straight into slot(rank) skip this)
+    if world > 1:
+        send = g.buffer[rank * stride: (rank + 1) * stride]          # the whole slot: its unused tail travels as padding
+        dist.all_gather_into_tensor(g.buffer, send, group=group)
+    return g
+
+
+def alloc_gather(n_tiles: int, block_shape: Sequence[int], dtype, device, group=None, costs: Optional[Sequence[float]] = None) -> GatheredBlocks:
+    """The gather buffer of ``gather_blocks_padded`` ahead of the compute, so that a rank's kernels write their blocks straight into
+    ``slot(rank)`` (``UNetEngine.segment_tiles(out=...)``)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    bounds = _tile_bounds(n_tiles, world, costs)
+    stride = max(bounds[r + 1] - bounds[r] for r in range(world))
+    return GatheredBlocks(torch.empty((world * stride, *[int(v) for v in block_shape]), dtype=dtype, device=device), bounds, stride)
+
+
+def gather_blocks(local_blocks: torch.Tensor, n_tiles: int, group=None, costs: Optional[Sequence[float]] = None) -> torch.Tensor:
+    """all_gather the per-rank centre blocks [n_local, C, ez, ey, ex] into ONE tensor [n_tiles, C, ez, ey, ex] in stitch order
+    (ranges are contiguous and ordered by rank).  Convenience form of ``gather_blocks_padded`` for callers that want the plain
+    tensor: ragged ranges cost one compacting copy here, none through ``GatheredBlocks`` + ``UNetEngine.stitch``."""
     if not dist.is_initialized():
         return local_blocks
-    rank = dist.get_rank(group)
-    counts = [tile_range_for_rank(n_tiles, r, world, costs) for r in range(world)]
-    max_n = max(e - b for b, e in counts)
-    tail = local_blocks.shape[1:]
-    if counts[rank][1] - counts[rank][0] != local_blocks.shape[0]:
-        raise ValueError("local block count does not match this rank's tile range")
-    send = local_blocks
-    if send.shape[0] < max_n:
-        pad = torch.zeros((max_n - send.shape[0], *tail), dtype=send.dtype, device=send.device)
-        send = torch.cat([send, pad], 0)
-    send = send.contiguous()
-    out = torch.empty((world * max_n, *tail), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(out, send, group=group)
-    if all(e - b == max_n for b, e in counts):
-        return out
-    pieces = [out[r * max_n: r * max_n + (e - b)] for r, (b, e) in enumerate(counts)]
-    return torch.cat(pieces, 0)
+    return gather_blocks_padded(local_blocks, n_tiles, group, costs).compact()
 
 
-def segment_tile_sharded(compute_blocks: Callable[[Tuple[int, int]], torch.Tensor], n_tiles: int, group=None,
-                         costs: Optional[Sequence[float]] = None) -> torch.Tensor:
-    """Every rank computes its tile range (balanced by ``costs`` when given), then all ranks hold all blocks."""
+def segment_tile_sharded(compute_blocks: Callable[..., torch.Tensor], n_tiles: int, group=None,
+                         costs: Optional[Sequence[float]] = None, block_shape: Optional[Sequence[int]] = None, dtype=torch.float32,
+                         device=None):
+    """Every rank computes its tile range (balanced by ``costs`` when given), then all ranks hold all blocks.
+
+    ``block_shape`` None: ``compute_blocks(rng)`` returns the rank's blocks, the result is the plain [n_tiles, ...] tensor.
+    ``block_shape`` = (C, ez, ey, ex): the gather buffer is allocated first, ``compute_blocks(rng, out)`` writes into this rank's slot
+    of it, the collective runs in place and the result is a ``GatheredBlocks`` (no copy on either side of the collective)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     rng = tile_range_for_rank(n_tiles, rank, world, costs)
-    return gather_blocks(compute_blocks(rng), n_tiles, group, costs)
+    if block_shape is None:
+        return gather_blocks(compute_blocks(rng), n_tiles, group, costs)
+    g = alloc_gather(n_tiles, block_shape, dtype, device, group, costs)
+    mine = g.slot(rank)
+    got = compute_blocks(rng, mine)
+    return gather_blocks_padded(mine if got is None else got, n_tiles, group, costs, into=g)
 
 
 # ---- input distribution, z-slab sharded resample, flag agreement (SURVEY.md 8e) ------------------------------------------------
@@ -115,7 +220,10 @@ def slab_range_for_rank(n_slices: int, rank: int, world: int) -> Tuple[int, int]
 
 def gather_slabs(local: torch.Tensor, n_slices: int, group=None) -> torch.Tensor:
     """all_gather z-slabs ``local`` [C, z_r, H, W] (rank r holds ``slab_range_for_rank(n_slices, r, world)``) into [C, n_slices, H, W].
-    One collective; ragged slabs are padded to the largest."""
+    One collective PER MAP, each gathering contiguous [z_r, H, W] slabs straight from the resample kernel's [C][z][y][x] output into the
+    result's [C][z][y][x] -- no transpose on either side (the one-collective form moved 2 x 189 MB through two transposes around a
+    189 MB gather; VERDICT r4 #4b).  Equal slabs (160 atlas slices over 8 ranks): the collective writes the result in place.  Ragged
+    slabs are gathered into ``max`` slices per rank and compacted with one copy per map."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -124,14 +232,23 @@ def gather_slabs(local: torch.Tensor, n_slices: int, group=None) -> torch.Tensor
         raise ValueError("local slab does not match this rank's z range")
     max_n = max(e - b for b, e in ranges)
     Cn, _, H, W = local.shape
-    send = local.transpose(0, 1).contiguous()                      # [z, C, H, W]: slices are the gathered unit
-    if send.shape[0] < max_n:
-        send = torch.cat([send, torch.zeros((max_n - send.shape[0], Cn, H, W), dtype=send.dtype, device=send.device)], 0)
-    out = torch.empty((world * max_n, Cn, H, W), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(out, send, group=group)
-    if not all(e - b == max_n for b, e in ranges):
-        out = torch.cat([out[r * max_n: r * max_n + (e - b)] for r, (b, e) in enumerate(ranges)], 0)
-    return out.transpose(0, 1).contiguous()
+    equal = all(e - b == max_n for b, e in ranges)
+    out = torch.empty((Cn, n_slices, H, W), dtype=local.dtype, device=local.device)
+    local = local.contiguous()
+    for c in range(Cn):
+        if equal:
+            dist.all_gather_into_tensor(out[c], local[c], group=group)
+            continue
+        send = local[c]
+        if send.shape[0] < max_n:
+            buf = torch.zeros((max_n, H, W), dtype=local.dtype, device=local.device)
+            buf[:send.shape[0]] = send
+            send = buf
+        padded = torch.empty((world * max_n, H, W), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(padded, send, group=group)
+        for r, (b, e) in enumerate(ranges):
+            out[c, b:e] = padded[r * max_n: r * max_n + (e - b)]
+    return out
 
 
 def any_rank(flag: torch.Tensor, group=None) -> torch.Tensor:
@@ -209,20 +326,35 @@ _cal_serial = 0
 
 def sync_calibration(engine, calibrate_fn: Callable[[], None], store=None, name: Optional[str] = None, rank: Optional[int] = None,
                      world: Optional[int] = None) -> List[int]:
-    """Every rank leaves with RANK 0's activation exponents: rank 0 calibrates (``calibrate_fn()``, unless its engine already holds a
-    calibration -- e.g. from the checkpoint's sidecar file) and publishes the 18 exponents on the process group's key-value store;
-    the other ranks wait for the key and ``set_act_exponents``.  Without this every rank of ``process_cohort`` would calibrate on
-    the first volume the queue happens to hand it, and a volume's last bits would depend on which rank claimed it.  No process
-    group: just ``calibrate_fn()`` when needed.  ``engine`` needs ``act_exponents()``, ``set_act_exponents()`` (UNetEngine)."""
+    """Every rank leaves with RANK 0's calibration OUTCOME -- not only its exponents: rank 0 calibrates (``calibrate_fn()``,
+    unless its engine already holds a verdict -- e.g. exponents from the checkpoint's sidecar file) and publishes ONE status on the process
+    group's key-value store; the other ranks wait for the key and mirror it:
+
+        "calibrated"   exponents set on every rank (``set_act_exponents``)
+        "refused_f32"  the calibration did not settle on rank 0: EVERY rank runs exact fp32 (``refuse_fp16``) -- otherwise rank 0 would run
+                       f32 and the others fp16x3 with exponents of their own first volume: the rank-dependence this function removes
+        "no_census"    the network records no range census (narrow test networks): exponents stay 0 everywhere, nobody calibrates again
+        "error"        ``calibrate_fn`` raised on rank 0: the message is published (a key is ALWAYS published, so nobody sits in
+                       ``store.wait`` until the store's timeout) and every rank raises
+
+    Without this every rank of ``process_cohort`` would calibrate on the first volume the queue happens to hand it, and a volume's last bits
+    would depend on which rank claimed it.  No process group: just ``calibrate_fn()`` when needed.  ``engine`` needs ``act_exponents()``,
+    ``set_act_exponents()`` and -- UNetEngine has them; optional on stand-ins -- ``calibration_status()``, ``refuse_fp16()``,
+    ``mark_no_census()``, ``effective_precision``."""
     global _cal_serial
     import json
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    exps, cal = engine.act_exponents()
+
+    def status_of(eng) -> str:                          # one source of "calibrated?": the engine's own verdict when it has one
+        if hasattr(eng, "calibration_status"):
+            return eng.calibration_status()
+        return "calibrated" if eng.act_exponents()[1] else "uncalibrated"
+
     if world == 1 and store is None:
-        if not cal:
+        if status_of(engine) == "uncalibrated":
             calibrate_fn()
         return engine.act_exponents()[0]
     if store is None:
@@ -232,16 +364,36 @@ def sync_calibration(engine, calibrate_fn: Callable[[], None], store=None, name:
         name = f"oai_fp16cal_{_cal_serial}"
         _cal_serial += 1
     if rank == 0:
-        if not cal:
-            calibrate_fn()
-        exps, cal = engine.act_exponents()
-        store.set(name, json.dumps({"act_exponents": exps, "calibrated": bool(cal),
-                                    "weights_sha256": getattr(engine, "weights_sha256", None)}))
-        return exps
+        doc = {"weights_sha256": getattr(engine, "weights_sha256", None)}
+        try:
+            if status_of(engine) == "uncalibrated":
+                calibrate_fn()
+            st = status_of(engine)
+            if st == "uncalibrated":                    # calibrate_fn returned without a verdict: treat as an error, never publish "go on as you are"
+                raise RuntimeError("calibrate_fn left the engine uncalibrated")
+            doc.update(status=st, act_exponents=engine.act_exponents()[0], precision=getattr(engine, "effective_precision", None))
+        except Exception as exc:                        # noqa: BLE001 - whatever went wrong, the other ranks must hear about it
+            doc.update(status="error", message=f"{type(exc).__name__}: {exc}")
+            store.set(name, json.dumps(doc))
+            raise
+        store.set(name, json.dumps(doc))
+        return doc["act_exponents"]
     store.wait([name])
     doc = json.loads(store.get(name))
+    if doc.get("status") == "error":
+        raise RuntimeError(f"sync_calibration: the calibration failed on rank 0 ({doc.get('message')})")
     if doc.get("weights_sha256") != getattr(engine, "weights_sha256", None):
         raise RuntimeError("sync_calibration: rank 0 holds other weights than this rank")
-    if doc["calibrated"]:
+    st = doc["status"]
+    if st == "calibrated":
         engine.set_act_exponents(doc["act_exponents"])
+    elif st == "refused_f32":
+        if not hasattr(engine, "refuse_fp16"):
+            raise RuntimeError("sync_calibration: rank 0 refused fp16x3 and this engine cannot mirror it")
+        engine.refuse_fp16("mirrored from rank 0")
+    elif st == "no_census":
+        if hasattr(engine, "mark_no_census"):
+            engine.mark_no_census()
+    else:
+        raise RuntimeError(f"sync_calibration: unknown status {st!r} from rank 0")
     return doc["act_exponents"]

@@ -91,8 +91,11 @@ class VolumePipeline:
     # ---- one volume, one GPU --------------------------------------------------------------------------------------------------
     def run(self, vol: torch.Tensor, meta_A: Image, check: bool = True) -> VolumeResult:
         res = self._run_overlapped(vol, meta_A) if self.overlap_registration else self._run_serial(vol, meta_A)
-        if check and res.overflow is not None and int(res.overflow.item()):
-            return self.rerun_f32(vol, meta_A)
+        if check and res.overflow is not None:
+            raised = bool(int(res.overflow.item()))
+            self.unet.note_volume_flag(raised)              # (a calibration FILE that keeps missing the data is dropped after three volumes in a row)
+            if raised:
+                return self.rerun_f32(vol, meta_A)
         return res
 
     def rerun_f32(self, vol: torch.Tensor, meta_A: Image, sharded_group="none") -> VolumeResult:
@@ -138,9 +141,13 @@ class VolumePipeline:
         from . import parallel
         _, _, n_tiles = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
         costs = self.unet.tile_costs(vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)     # border tiles are cheaper: balance the work
-        blocks = parallel.segment_tile_sharded(
-            lambda rng: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx), n_tiles, group, costs)
-        return self.unet.stitch(blocks, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
+        eff, _, _ = tile_grid(vol.shape, self.tile_zyx, self.overlap_zyx)
+        # the kernels write this rank's blocks straight into its slot of the gather buffer, the collective runs in place, and the stitch
+        # reads the (ragged: 19-23 tiles per rank) buffer through a table: no copy on either side of the all_gather
+        gathered = parallel.segment_tile_sharded(
+            lambda rng, out: self.unet.segment_tiles(vol, self.tile_zyx, self.overlap_zyx, rng, 0, self.batch, self.crop_zyx, out=out),
+            n_tiles, group, costs, block_shape=(self.unet.n_classes, *eff), dtype=torch.float32, device=self.unet.device)
+        return self.unet.stitch(gathered, vol.shape, self.tile_zyx, self.overlap_zyx, self.crop_zyx)
 
     def run_sharded(self, vol: Optional[torch.Tensor], meta_A: Image, group=None, src: int = 0, check: bool = True) -> VolumeResult:
         """``vol`` is needed on rank ``src`` only (others may pass None): broadcast -> tile-sharded segmentation + all_gather ->
@@ -181,6 +188,9 @@ class VolumePipeline:
         local = self.resample(maps, phi, meta_A, parallel.slab_range_for_rank(nz, rank, world))
         atlas_maps = parallel.gather_slabs(local, nz, group)
         res = VolumeResult(maps[0], maps[1], phi, atlas_maps[0], atlas_maps[1], flag)
-        if check and flag is not None and int(flag.item()):
-            return self.rerun_f32(vol, meta_A, sharded_group=group)
+        if check and flag is not None:
+            raised = bool(int(flag.item()))                 # (the same verdict on every rank: the state was MAX-reduced)
+            self.unet.note_volume_flag(raised)
+            if raised:
+                return self.rerun_f32(vol, meta_A, sharded_group=group)
         return res

@@ -294,6 +294,37 @@ class IconEngine:
         return phi_AB, phi_BA
 
 
+def _has_nontrivial_batchnorm(state_dict) -> bool:
+    """True if any ``batchNorms.*`` tensor of the checkpoint differs from a freshly constructed BatchNorm3d (gamma 1, beta 0, running mean 0,
+    running variance 1): only then does applying or skipping it change phi."""
+    for k, v in state_dict.items():
+        if ".batchNorms." not in k and not k.startswith("batchNorms."):
+            continue
+        t = torch.as_tensor(v).float()
+        if k.endswith("num_batches_tracked"):
+            continue
+        want = 1.0 if (k.endswith(".weight") or k.endswith("running_var")) else 0.0
+        if t.numel() and float((t - want).abs().max()) > 1e-6:
+            return True
+    return False
+
+
+_BN_WARNED = False
+
+
+def _warn_bn_assumption_once() -> None:
+    global _BN_WARNED
+    if _BN_WARNED:
+        return
+    _BN_WARNED = True
+    import warnings
+    warnings.warn("ICON_Registration: this checkpoint holds BatchNorm tensors that are NOT the identity, and `apply_bn` was not stated.  They are "
+                  "NOT applied -- assumption: icon_registration 1.1.2's UNet2.forward has `x = self.batchNorms[depth](x)` commented out (the package "
+                  "is not installed here, so this cannot be checked; tests/test_icon_pin_gpu.py checks it wherever the package imports).  If the "
+                  "package does apply them, phi is wrong: pass apply_bn=True (or OAI_ICON_APPLY_BN=1).  Pass apply_bn=False to silence this.",
+                  stacklevel=3)
+
+
 class ICON_Registration:
     """Drop-in for oai_analysis.registration.ICON_Registration (registration.py:18-27).
 
@@ -302,7 +333,13 @@ class ICON_Registration:
     """
 
     def __init__(self, weights=None, net_shape: Sequence[int] = NET_SHAPE, device=None, verbose: bool = True,
-                 apply_bn: bool = False, pad_front: bool = True):
+                 apply_bn: Optional[bool] = None, pad_front: bool = True):
+        """``apply_bn``: whether the eval-mode BatchNorm3d behind every up-conv of ``tallUNet2`` is applied.  This cannot be verified here
+        (``icon_registration`` 1.1.2 is neither vendored nor installed; two independent recollections have the call commented out in
+        ``UNet2.forward``), so it is NOT a silent default: state it -- ``apply_bn=True / False`` or ``$OAI_ICON_APPLY_BN=1 / 0`` --
+        or, unstated, the BatchNorm is skipped and a checkpoint whose BatchNorm tensors are not the identity (trained statistics that
+        would change phi) gets ONE prominent warning naming the assumption.  ``tests/test_icon_pin_gpu.py`` settles it against the
+        package itself the first time an environment has ``icon_registration`` importable."""
         import os
         if weights is None:
             root = os.environ.get("OAI_DATA_DIR")
@@ -313,6 +350,12 @@ class ICON_Registration:
             if not os.path.isfile(weights):
                 raise ValueError(f"=> no checkpoint found at '{weights}'")
             weights = torch.load(weights, map_location="cpu")
+        if apply_bn is None and os.environ.get("OAI_ICON_APPLY_BN", "") in ("0", "1"):
+            apply_bn = os.environ["OAI_ICON_APPLY_BN"] == "1"
+        if apply_bn is None:
+            apply_bn = False
+            if _has_nontrivial_batchnorm(weights):
+                _warn_bn_assumption_once()
         self.register_module = IconEngine(weights, net_shape, device, apply_bn=apply_bn, pad_front=pad_front)
         self.verbose = verbose
 

@@ -83,6 +83,7 @@ class UNetEngine:
                           f"{name}.1.running_mean", f"{name}.1.running_var", f"{name}.1.num_batches_tracked"}
             for t in keep[n_before - 1:]:
                 digest.update(t.numpy().tobytes())
+        digest.update(np.float32(bn_eps).tobytes())       # folded into the packed epilogue affine: part of "the network as the kernels see it" 
         self.weights_sha256 = digest.hexdigest()
         extra = set(state_dict) - known
         if extra:
@@ -99,10 +100,65 @@ class UNetEngine:
         self.auto_calibrate = True
         self._calibrated = False
         self._fp16_refused = False      # calibration did not settle for this network: "fp16x3" requests run "f32" (with a warning)
-        self.calibration_file: Optional[str] = None     # JSON sidecar (set_calibration_file): read now, written after a calibration
+        self._no_census_net = False     # no layer of this network records a range census (widths not multiples of 16): nothing to calibrate from
+        self.calibration_file: Optional[str] = None     # JSON sidecar (set_calibration_file): read when it exists; written only when calibration_write is set
+        self.calibration_write = False                  # write the sidecar after a successful calibrate() -- opt-in (no side-effect writes next to user checkpoints)
         self.calibration_source = "none"                # "none" | "file" | "set" | "calibrated"
+        self.calibration_census = None                  # per-layer maxima the exponents were chosen from (None when they were set / read from an old file)
+        self._flag_streak = 0                           # consecutive volumes that raised the range flag under a calibration read from a file (note_volume_flag)
         if precision != "f32":
             self.set_precision(precision)
+
+    # ---- what arithmetic this engine REALLY runs (callers label results from this, not from the string they asked for) ----------
+    @property
+    def effective_precision(self) -> str:
+        """The arithmetic the next launch runs: the requested precision, or "f32" after a refused fp16x3 calibration."""
+        return self.precision
+
+    @property
+    def fp16_refused(self) -> bool:
+        """True when this network's activations did not fit the fp16x3 window at any exponents: every "fp16x3" request runs "f32"."""
+        return self._fp16_refused
+
+    def calibration_status(self) -> str:
+        """ONE source for "is this engine calibrated": "refused_f32" | "no_census" | "calibrated" | "uncalibrated"."""
+        if self._fp16_refused:
+            return "refused_f32"
+        if self._no_census_net:
+            return "no_census"
+        return "calibrated" if (self._calibrated or self.act_exponents()[1]) else "uncalibrated"
+
+    def refuse_fp16(self, reason: str = "") -> None:
+        """Mirror of a failed calibration (another rank's, parallel.sync_calibration): this engine runs "f32" from now on."""
+        if not self._fp16_refused:
+            warnings.warn(f"fp16x3 refused for this engine ({reason or 'calibration did not settle'}): it runs precision 'f32'")
+        self._fp16_refused = True
+        self.set_precision("f32")
+
+    def mark_no_census(self) -> None:
+        """Mirror of "this network records no census": exponents stay 0, nobody calibrates again."""
+        self._no_census_net = True
+        self._calibrated = True
+        self.calibration_source = "none"
+
+    def note_volume_flag(self, raised: bool, limit: int = 3) -> bool:
+        """Per-volume bookkeeping of the callers that repeat a flagged volume in fp32: ``limit`` CONSECUTIVE flagged volumes under a
+        calibration that came from a file mean the file does not describe this data (an unrepresentative first volume pinned its
+        exponents: every later volume would pay the fp32 repeat, silently, forever -- ADVICE r4).  The file is then ignored: the
+        engine recalibrates on the next volume it sees (and rewrites the file only if calibration_write is set).  Returns True when
+        that happened."""
+        if not raised:
+            self._flag_streak = 0
+            return False
+        self._flag_streak += 1
+        if self._flag_streak >= limit and self.calibration_source == "file" and not self._fp16_refused:
+            warnings.warn(f"{self._flag_streak} consecutive volumes left the range window of the fp16x3 calibration read from "
+                          f"{self.calibration_file}: ignoring that file and recalibrating on the next volume")
+            self._calibrated = False
+            self.calibration_source = "none"
+            self._flag_streak = 0
+            return True
+        return False
 
     def set_precision(self, precision: str) -> None:
         """Arithmetic of the 3x3x3 conv layers: "f32" (exact fp32 MFMA), "fp16x3" (fp32-grade split fp16, the default of the
@@ -197,13 +253,15 @@ class UNetEngine:
         self.calibration_source = "set"
 
     # ---- a calibration belongs to a checkpoint, not to the first volume a process happens to see -----------
-    def save_calibration(self, path: str, note: str = "") -> None:
-        """JSON sidecar: the 18 exponents + the sha256 of the network's parameters.  Written atomically (temp file + rename): ranks
-        that calibrate at the same time leave one complete file, whichever wins."""
+    def save_calibration(self, path: str, note: str = "", volume_id: Optional[str] = None) -> None:
+        """JSON sidecar: the 18 exponents + the sha256 of the network's parameters (and bn_eps) + what they were chosen from -- the
+        per-layer maxima of the calibration census and, when the caller names it, the identity of the calibration volume.  Written
+        atomically (temp file + rename): ranks that calibrate at the same time leave one complete file, whichever wins."""
         exps, cal = self.act_exponents()
         if not cal:
             raise _lib.OaiError("save_calibration: the engine is not calibrated")
-        doc = {"format": 1, "precision": "fp16x3", "weights_sha256": self.weights_sha256, "act_exponents": exps, "note": note}
+        doc = {"format": 1, "precision": "fp16x3", "weights_sha256": self.weights_sha256, "act_exponents": exps, "note": note,
+               "census_max": self.calibration_census, "volume_id": volume_id or getattr(self, "calibration_volume_id", None)}
         tmp = f"{path}.tmp.{os.getpid()}"
         with open(tmp, "w") as f:
             json.dump(doc, f)
@@ -232,12 +290,15 @@ class UNetEngine:
             warnings.warn(f"fp16x3 calibration file {path} holds exponents the library refuses ({exc}): ignoring it")
             return False
         self.calibration_source = "file"
+        self.calibration_census = doc.get("census_max")
+        self._flag_streak = 0
         return True
 
-    def set_calibration_file(self, path: Optional[str]) -> bool:
-        """Use ``path`` as this engine's calibration sidecar: read it now if it exists (returns True when its exponents were taken),
-        and write it after the next successful calibrate().  None detaches."""
+    def set_calibration_file(self, path: Optional[str], write: bool = False) -> bool:
+        """Use ``path`` as this engine's calibration sidecar: read it now if it exists (returns True when its exponents were taken).
+        ``write=True`` (opt-in): also write it after the next successful calibrate().  None detaches."""
         self.calibration_file = path
+        self.calibration_write = bool(path) and bool(write)
         return bool(path) and not self._calibrated and self.load_calibration(path)
 
     def calibrate(self, run_pass, max_passes: int = 24) -> int:
@@ -252,19 +313,21 @@ class UNetEngine:
             for n in range(1, max_passes + 1):
                 run_pass()
                 more = C.c_int(0)
+                seen = [float(v) for v in self.census(reset=False)]        # (what this pass stored: the sidecar records the settled pass's maxima)
                 rc = self.lib.oai_unet_calibrate_step(self._h, st, C.byref(more))
                 if rc != 0 and n == 1 and b"census is empty" in (self.lib.oai_last_error() or b""):
                     # no layer of this network runs through a census-recording kernel (widths that are not multiples of 16: test networks
                     # only): there is nothing to calibrate from and no LOW bit; the exponents stay 0, as before the calibration existed
                     warnings.warn("this network records no range census (layer widths not multiples of 16): fp16x3 runs with activation exponents 0")
-                    self._calibrated = True
-                    self.calibration_source = "none"
+                    self.mark_no_census()
                     return 0
                 _lib.check(rc, "oai_unet_calibrate_step")
                 if not more.value:
                     self._calibrated = True
                     self.calibration_source = "calibrated"
-                    if self.calibration_file:
+                    self._flag_streak = 0
+                    self.calibration_census = seen
+                    if self.calibration_file and self.calibration_write:
                         try:
                             self.save_calibration(self.calibration_file, note=f"calibrated in {n} passes")
                         except OSError as exc:          # a read-only model directory is not an error: the next process calibrates again
@@ -273,9 +336,7 @@ class UNetEngine:
         # not settled: this network's activations do not fit the fp16x3 window at any exponents (a layer whose range spans more than
         # the window, non-finite values, ...).  Before the calibration existed such a checkpoint ran through the fp32 repeat; keep that
         # behaviour instead of raising: every later "fp16x3" request of this engine runs exact fp32.
-        warnings.warn(f"fp16x3 calibration did not settle in {max_passes} passes (census {self.census()}): this engine runs precision 'f32'")
-        self._fp16_refused = True
-        self.set_precision("f32")
+        self.refuse_fp16(f"calibration did not settle in {max_passes} passes, census {self.census()}")
         return -1
 
     def _needs_calibration(self) -> bool:
@@ -331,10 +392,11 @@ class UNetEngine:
             raise ValueError("tiles must be [B,1,D,H,W]")
         tiles = tiles.to(self.device, torch.float32).contiguous()
         B, _, d, h, w = tiles.shape
-        ws = self._workspace((d, h, w), min(B, batch or self.auto_batch((d, h, w), B)))      # the C side loops over what the workspace holds
+        nb = min(B, batch or self.auto_batch((d, h, w), B))
         out = torch.empty((B, self.n_classes, d, h, w), dtype=torch.float32, device=self.device)
 
         def launch():
+            ws = self._workspace((d, h, w), nb)      # (sized per launch: a refused calibration switches the arithmetic in between; the C side loops over what the workspace holds)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.oai_unet_forward_tiles(self._h, tiles.data_ptr(), out.data_ptr(), B, d, h, w,
                                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
@@ -357,11 +419,12 @@ class UNetEngine:
         return list(out)
 
     def segment_tiles(self, vol: torch.Tensor, tile_zyx, overlap_zyx, tile_range: Optional[Tuple[int, int]] = None,
-                      out_mode: int = 0, batch: Optional[int] = None, crop_zyx=None) -> torch.Tensor:
+                      out_mode: int = 0, batch: Optional[int] = None, crop_zyx=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Kept-centre blocks [n_local, n_classes, ez, ey, ex] of tiles [begin,end) of the volume.
 
         ``crop_zyx``: the frame ``stitch`` will zero; block voxels inside it (and beyond the image) are not computed
-        and hold unspecified values."""
+        and hold unspecified values.  ``out``: write the blocks there (a contiguous fp32 tensor of exactly that shape on this device --
+        e.g. this rank's slot of an all_gather buffer, parallel.alloc_gather) instead of allocating."""
         vol = vol.to(self.device, torch.float32).contiguous()
         D, H, W = vol.shape
         eff, grid, ntiles = tile_grid((D, H, W), tile_zyx, overlap_zyx)
@@ -374,7 +437,12 @@ class UNetEngine:
             # on the WHOLE volume whatever range was asked for: every rank of a tile-sharded volume arrives at the same exponents
             self.calibrate_volume(vol, tile_zyx, overlap_zyx, crop_zyx, batch=None if (begin, end) != (0, ntiles) else batch)
         ws = self._workspace(tile_zyx, batch, (D, H, W), overlap_zyx)
-        blocks = torch.empty((end - begin, self.n_classes, *eff), dtype=torch.float32, device=self.device)
+        if out is not None:
+            if tuple(out.shape) != (end - begin, self.n_classes, *eff) or out.dtype != torch.float32 or out.device != self.device or not out.is_contiguous():
+                raise ValueError("out must be a contiguous float32 tensor [n_local, n_classes, ez, ey, ex] on the engine's device")
+            blocks = out
+        else:
+            blocks = torch.empty((end - begin, self.n_classes, *eff), dtype=torch.float32, device=self.device)
         if end > begin:
             self._launch_segment(vol, tile_zyx, overlap_zyx, crop_zyx, begin, end, out_mode, blocks, batch, ws)
         return blocks
@@ -397,15 +465,29 @@ class UNetEngine:
         blocks = torch.empty((ntiles, self.n_classes, *eff), dtype=torch.float32, device=self.device)
         return self.calibrate(lambda: self._launch_segment(vol, tile_zyx, overlap_zyx, crop_zyx, 0, ntiles, 0, blocks, batch, ws))
 
-    def stitch(self, blocks: torch.Tensor, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None) -> torch.Tensor:
-        """maps[n_classes, D, H, W] (Partition.assemble, non-vote branch)."""
+    def stitch(self, blocks, size_zyx, tile_zyx, overlap_zyx, crop_zyx=None) -> torch.Tensor:
+        """maps[n_classes, D, H, W] (Partition.assemble, non-vote branch).  ``blocks``: the [n_tiles, n_classes, ez, ey, ex] tensor, or
+        the ``parallel.GatheredBlocks`` an all_gather of per-rank tile ranges left behind (read in place, oai_stitch_blocks_ranged)."""
         D, H, W = (int(v) for v in size_zyx)
         eff, grid, ntiles = tile_grid((D, H, W), tile_zyx, overlap_zyx)
+        maps = torch.empty((self.n_classes, D, H, W), dtype=torch.float32, device=self.device)
+        crop = _lib.int3(crop_zyx) if crop_zyx is not None else None
+        if hasattr(blocks, "bounds") and hasattr(blocks, "buffer"):          # GatheredBlocks
+            g = blocks
+            if g.n_tiles != ntiles:
+                raise ValueError(f"stitch needs the blocks of all {ntiles} tiles, the gather holds {g.n_tiles}")
+            buf = g.buffer
+            if not buf.is_contiguous() or buf.device != self.device or buf.dtype != torch.float32:
+                raise ValueError("the gather buffer must be a contiguous float32 tensor on the engine's device")
+            bounds = (C.c_int * len(g.bounds))(*g.bounds)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.oai_stitch_blocks_ranged(buf.data_ptr(), self.n_classes, D, H, W, _lib.int3(tile_zyx), _lib.int3(overlap_zyx),
+                                                             crop, bounds, len(g.bounds) - 1, g.stride, maps.data_ptr(),
+                                                             torch.cuda.current_stream().cuda_stream), "oai_stitch_blocks_ranged")
+            return maps
         if blocks.shape[0] != ntiles:
             raise ValueError(f"stitch needs the blocks of all {ntiles} tiles, got {blocks.shape[0]}")
         blocks = blocks.contiguous()
-        maps = torch.empty((self.n_classes, D, H, W), dtype=torch.float32, device=self.device)
-        crop = _lib.int3(crop_zyx) if crop_zyx is not None else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.oai_stitch_blocks(blocks.data_ptr(), self.n_classes, D, H, W, _lib.int3(tile_zyx),
                                                   _lib.int3(overlap_zyx), crop, maps.data_ptr(),

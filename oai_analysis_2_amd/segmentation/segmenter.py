@@ -19,6 +19,13 @@ from .networks import get_network
 from .utils import initialize_model
 
 
+def _volume_id(vol) -> str:
+    """sha256 of a volume's fp32 voxels + its shape: the identity a calibration sidecar records."""
+    import hashlib
+    a = vol.detach().to("cpu", torch.float32).contiguous().numpy() if torch.is_tensor(vol) else np.ascontiguousarray(vol, dtype=np.float32)
+    return "x".join(str(v) for v in a.shape) + ":" + hashlib.sha256(a.tobytes()).hexdigest()
+
+
 def load_json_to_dict(json_file):
     """The training config is JSON (despite its .pth.tar name): segmenter.py:14-17, module_parameters.py:38-50."""
     with open(json_file) as f:
@@ -59,11 +66,15 @@ class Segmenter3DInPatch(Segmenter):
         self.model.to(self.device)
         self.model.eval()
         # fp16x3's activation exponents belong to the checkpoint, not to the first volume a process happens to see: config key
-        # "fp16_calibration_file" (default: "<ckpoint_path>.fp16cal.json"; False / "" = none) names a JSON sidecar -- 18 exponents +
-        # the sha256 of the parameters -- that is read here when it exists and written after the first calibration otherwise, so every
-        # process, rank and restart segments a given volume with the same arithmetic
+        # "fp16_calibration_file" (default: "<ckpoint_path>.fp16cal.json"; False / "" = none) names a JSON sidecar -- 18 exponents, the
+        # sha256 of the parameters (+ bn_eps), the census they were chosen from and the calibration volume's identity -- that is READ
+        # when it exists, so that every process, rank and restart segments a given volume with the same arithmetic.  It is WRITTEN only
+        # on request (no side-effect files next to a user's checkpoint, no exponents pinned by whatever volume came first):
+        # by `calibrate(image)` -- the explicit step, on a volume the caller chose as representative -- or, with config key
+        # "fp16_calibration_write": True, after the first automatic calibration.
         cal = self.config.get("fp16_calibration_file", str(self.config["ckpoint_path"]) + ".fp16cal.json")
         self.calibration_file = str(cal) if cal else None
+        self.calibration_write = bool(self.config.get("fp16_calibration_write", False))
         self.ready = True
 
     def train(self, *args, **kwargs):      # the reference's training entry points are stubs (segmenter.py:64-70)
@@ -97,18 +108,24 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         precision = self.config.get("precision", "fp16x3")
         if eng.precision != precision:
             eng.set_precision(precision)
-        if precision == "fp16x3" and eng.calibration_file != self.calibration_file:
-            eng.set_calibration_file(self.calibration_file)
+        if precision == "fp16x3" and (eng.calibration_file != self.calibration_file or eng.calibration_write != self.calibration_write):
+            eng.set_calibration_file(self.calibration_file, write=self.calibration_write)
+        if precision == "fp16x3" and self.calibration_write and eng.calibration_status() == "uncalibrated":
+            eng.calibration_volume_id = _volume_id(vol)             # what the sidecar will say it was calibrated on
         blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
                                    crop_zyx if min(crop_zyx) > 0 else None)
-        if precision == "fp16x3" and eng.range_overflow():
-            # outside the calibrated window (an activation beyond 65504, or a layer > 128 x quieter than at calibration): repeat this
-            # volume with exact fp32 MFMA arithmetic
-            print("WARNING: activations outside the fp16x3 range window, repeating the segmentation in fp32")
-            eng.set_precision("f32")
-            blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
-                                       crop_zyx if min(crop_zyx) > 0 else None)
-            eng.set_precision(precision)
+        # (eng.effective_precision: "f32" when this network's calibration was refused -- then there is no range window to leave)
+        if precision == "fp16x3" and eng.effective_precision == "fp16x3":
+            raised = eng.range_overflow()
+            eng.note_volume_flag(raised)                            # three flagged volumes in a row under a calibration FILE: the file is dropped, the next volume recalibrates
+            if raised:
+                # outside the calibrated window (an activation beyond 65504, or a layer > 128 x quieter than at calibration): repeat this
+                # volume with exact fp32 MFMA arithmetic
+                print("WARNING: activations outside the fp16x3 range window, repeating the segmentation in fp32")
+                eng.set_precision("f32")
+                blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
+                                           crop_zyx if min(crop_zyx) > 0 else None)
+                eng.set_precision(precision)
         if tile_range is not None:
             return blocks
         if min(crop_zyx) == 0:
@@ -117,6 +134,27 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         else:
             maps = eng.stitch(blocks, vol.shape, self.tile_zyx, ovl_zyx, crop_zyx)
         return maps if as_device_tensor else maps.cpu().numpy()
+
+    def calibrate(self, image, write: bool = True) -> dict:
+        """The explicit fp16x3 calibration step: choose the activation exponents on ``image`` -- a volume the caller picked as representative
+        of the cohort -- and (``write``) store them in the checkpoint's sidecar with the census and the volume's identity.  Every later
+        process that loads this checkpoint reads them instead of calibrating on whatever volume it happens to see first."""
+        if not self.ready:
+            self.pred_setup()
+        eng = self.model.engine
+        if eng.precision != "fp16x3":
+            eng.set_precision("fp16x3")
+        vol = torch.as_tensor(np.ascontiguousarray(as_image(image).array, dtype=np.float32)).to(eng.device)
+        ovl_xyz = tuple(int(v) for v in self.config["overlap_size"])
+        crop_zyx = (ovl_xyz[2], ovl_xyz[0], ovl_xyz[1])
+        eng.set_calibration_file(self.calibration_file, write=False)
+        eng._calibrated = False                                      # (an explicit request replaces whatever the file held)
+        eng.calibration_volume_id = _volume_id(vol)
+        passes = eng.calibrate_volume(vol, self.tile_zyx, ovl_xyz[::-1], crop_zyx if min(crop_zyx) > 0 else None)
+        if write and self.calibration_file and eng.calibration_status() == "calibrated":
+            eng.save_calibration(self.calibration_file, note=f"Segmenter.calibrate: {passes} passes")
+        return {"status": eng.calibration_status(), "passes": passes, "act_exponents": eng.act_exponents()[0], "census_max": eng.calibration_census,
+                "volume_id": eng.calibration_volume_id, "file": self.calibration_file if write else None}
 
     def segment(self, image, if_output_prob_map=False, if_output_itk=True):
         """(FC, TC) exactly like segmenter.py:100-131: float64 maps (prob) or bool-valued maps (mask)."""

@@ -202,3 +202,47 @@ def identity_map(shape_dhw) -> np.ndarray:
     for d, n in enumerate((D, H, W)):
         g[d] *= 1.0 / (n - 1)
     return g.astype(np.float32)
+
+
+def write_standin_asset_tree(root: str, golden_npz: str) -> dict:
+    """A stand-in for the reference's three release tarballs (oai_analysis/data.py:8-22, v2.0.0) in THEIR layout, from seeded synthetic data
+    and one reference-made fixture -- so that the code path of BASELINE config 1 (``AnalysisObject()`` / ``Segmenter3DInPatchClassWise`` ->
+    NIfTI in -> sum|d| against stored NIfTI maps, test/test_all.py:17-33) executes where the real assets cannot be downloaded:
+
+        models/segmentation_model.pth.tar            torch.save({"model_state_dict": ...})  -- the seeded network of the fixture
+        models/segmentation_train_config.pth.tar     the JSON training config (patch_size, model, model_setting)
+        models/icon_weights.pth                      a seeded three-step gradICON regis_net state dict
+        atlases/atlas_60_LEFT_baseline_NMI/atlas_image.nii.gz
+        test_data/colab_case/image_preprocessed.nii.gz, FC_probmap.nii.gz, TC_probmap.nii.gz
+
+    ``golden_npz`` = tests/golden/segment_small.npz: the REFERENCE's own ``Segmenter3DInPatchClassWise.segment`` output on the seeded
+    24 x 72 x 72 volume (tests/golden/make_golden.py), which becomes the stored FC / TC maps.  It pins nothing new; it proves the day-one
+    path runs.  Returns the config values a caller needs that the real tree fixes by convention (``overlap_size``: the fixture was made with
+    (8, 8, 4) on 32 x 32 x 16 patches, the released network uses (16, 16, 8) on 128 x 128 x 32)."""
+    import json
+    import os
+    from .image import Image
+    from .io_nifti import write_nifti
+    z = np.load(golden_npz)
+    shape = tuple(int(v) for v in z["fc_prob"].shape)
+    models = os.path.join(root, "models")
+    atlas_dir = os.path.join(root, "atlases", "atlas_60_LEFT_baseline_NMI")
+    case = os.path.join(root, "test_data", "colab_case")
+    for d in (models, atlas_dir, case):
+        os.makedirs(d, exist_ok=True)
+    torch.save({"model_state_dict": make_unet_state_dict(seed=int(z["weight_seed"])), "epoch": 1}, os.path.join(models, "segmentation_model.pth.tar"))
+    with open(os.path.join(models, "segmentation_train_config.pth.tar"), "w") as f:
+        json.dump({"patch_size": [int(v) for v in z["patch"]], "model": "UNet",
+                   "model_setting": {"in_channels": 1, "n_classes": 2, "bias": True, "BN": False}}, f)
+    torch.save(make_icon_state_dict(0, last_scale=0.1), os.path.join(models, "icon_weights.pth"))
+    spacing, origin = [0.36, 0.36, 0.7], [2.0, -3.0, 1.0]
+    vol = make_volume(int(z["volume_seed"]), shape)
+    write_nifti(os.path.join(case, "image_preprocessed.nii.gz"), Image(vol, spacing, origin))
+    write_nifti(os.path.join(case, "FC_probmap.nii.gz"), Image(z["fc_prob"].astype(np.float32), spacing, origin))
+    write_nifti(os.path.join(case, "TC_probmap.nii.gz"), Image(z["tc_prob"].astype(np.float32), spacing, origin))
+    write_nifti(os.path.join(atlas_dir, "atlas_image.nii.gz"), Image(make_volume(1000, shape), spacing, [0.0, 0.0, 0.0]))
+    info = {"overlap_size": [int(v) for v in z["overlap"]], "shape_zyx": list(shape), "source": os.path.basename(golden_npz),
+            "note": "stand-in asset tree (oai_analysis_2_amd.synth.write_standin_asset_tree): seeded synthetic data + the reference's own output on it"}
+    with open(os.path.join(root, "standin.json"), "w") as f:
+        json.dump(info, f)
+    return info

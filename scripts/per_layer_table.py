@@ -7,7 +7,10 @@ GF = {"ec1": 58.0, "ec2": 14.5, "ec3": 29.0, "ec4": 7.25, "ec5": 14.5, "ec6": 3.
 ORDER = ["ec1", "ec2", "ec3", "ec4", "ec5", "ec6", "ec7", "dc9 (up)", "dc8", "dc7", "dc6 (up)", "dc5", "dc4", "dc3 (up)", "dc2", "dc1"]
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-fused = [i for i, r in enumerate(rows) if "conv3_igemm_sres<" in r["Kernel_Name"] and "false, true" in r["Kernel_Name"]]
+def _targs(name):                                      # template arguments of conv3_igemm_sres<MREP, RX, RY, WY, WX, RING, FIRST, BLDS, M16>
+    if "conv3_igemm_sres<" not in name: return []
+    return [a.strip() for a in name.split("conv3_igemm_sres<", 1)[1].split(">", 1)[0].split(",")]
+fused = [i for i, r in enumerate(rows) if len(_targs(r["Kernel_Name"])) > 6 and _targs(r["Kernel_Name"])[6] == "true"]
 if fused: rows = rows[fused[-1]:]                        # ec0 fused into ec1 (per tile, or the shared pass over the padded volume): a pass starts at the FIRST instantiation
 else:
     starts = [i for i, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"]]

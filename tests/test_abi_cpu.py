@@ -111,8 +111,8 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
     # (c) the copy-out of the default conv kernel (and of its ec0-fused instantiation) is a run of stores with nothing in between that waits
     # for memory: `vmcnt` counts stores on this ISA, so a reload from scratch or a late load between them makes every store wait for all
     # earlier ones to reach memory (profiles/r02_conv_per_layer.md section 5).  Chunk loop: no scratch traffic at all.
-    for sym in ("_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb0ELb0EEEvNS_8ConvArgsEPKh",
-                "_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb1ELb0EEEvNS_8ConvArgsEPKh"):
+    for sym in ("_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb0ELb0ELb0EEEvNS_8ConvArgsEPKh",
+                "_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb1ELb0ELb0EEEvNS_8ConvArgsEPKh"):
         m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
         assert m, f"{sym} not in the library"
         body = m.group(1).split("\n")
@@ -170,3 +170,27 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
         assert len(loads) >= 40 and all("s[" in ln.split("//")[0] for ln in loads), "a fragment load that is not the SGPR-base asm form"
     # (the two-group form's halo pieces also come from an SGPR base + 32-bit offset; the specialised form's stagers keep the per-lane 64-bit form)
     assert all("s[" in ln.split("//")[0] for ln in re.search(r"^[0-9a-f]+ <_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1EEEvNS_8ConvArgsEPKh>:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M).group(1).split("\n") if "global_load_lds_dwordx4" in ln)
+    # (g) round 5: the direct kernel on 16x16x32 tap pairs (conv3_igemm_sres<..., M16>, default for the layers with Cout % 128 != 0): 14 steps of
+    # 96 / 64 MFMAs per chunk for ML = 4 (1312 + 984 + 656 + 328), no 32x32x16, no scratch in a tap stream, every fragment load the SGPR-base asm
+    # form -- and NO BRANCH WHILE A FRAGMENT LOAD IS IN FLIGHT: an inline-asm load is invisible to the compiler (it believes the result register
+    # holds the value from the asm statement on), so a load in flight across a control-flow edge can be copied (`v_mov` of a stale register) or its
+    # register re-used.  A first version requested the next chunk's fragments during the last step and the first chunk's in the prologue: the
+    # pre-headers of the ML = 1 / 3 loop variants copied the in-flight registers -- intermittently wrong results at small tile levels.
+    for sym, first in (("_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb0ELb0ELb1EEEvNS_8ConvArgsEPKh", False),
+                       ("_ZN3oai16conv3_igemm_sresILi4ELi16ELi2ELi4ELi1ELb0ELb1ELb0ELb1EEEvNS_8ConvArgsEPKh", True)):
+        m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
+        assert m, f"{sym} not in the library"
+        body = [ln.split("//")[0] for ln in m.group(1).split("\n")]
+        mf_i = [i for i, ln in enumerate(body) if "v_mfma_f32_16x16x32_f16" in ln]
+        assert len(mf_i) == (1312 if first else 3280) and not [ln for ln in body if "v_mfma_f32_32x32x16_f16" in ln]
+        assert not [ln for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside a tap stream of the direct 16x16x32 form"
+        loads = [ln for ln in body if "global_load_dwordx4" in ln and "lds" not in ln]
+        assert len(loads) >= 100 and all("s[" in ln for ln in loads), "a fragment load that is not the SGPR-base asm form"
+        in_flight = False
+        for ln in body:
+            if "global_load_dwordx4" in ln and "lds" not in ln:
+                in_flight = True
+            elif "s_waitcnt" in ln and "vmcnt(0)" in ln:
+                in_flight = False
+            elif in_flight and ("s_cbranch" in ln or "s_branch" in ln or "s_setpc" in ln):
+                raise AssertionError(f"{sym}: a branch while an inline-asm fragment load is in flight: {ln.strip()}")

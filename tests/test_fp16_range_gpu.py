@@ -215,11 +215,21 @@ def test_calibration_is_persisted_next_to_the_checkpoint_and_shared_between_work
     # volume a: the usual knee-like range; volume b: 6 x quieter, so a worker calibrating on it picks other exponents
     va, vb, vc = make_volume(1, shape), make_volume(2, shape) * 0.15, make_volume(3, shape)
     sidecar = os.path.join(td, "segmentation_model.pth.tar.fp16cal.json")
-    w1 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
+    #  by default nothing is written next to the checkpoint: a worker calibrates for itself
+    w0 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
+    w0.segment_array(va, True)
+    assert not os.path.exists(sidecar) and w0.model.engine.calibration_source == "calibrated"
+    # opt-in ("fp16_calibration_write"): the first calibration is stored, with what it was chosen from
+    w1 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td, fp16_calibration_write=True))
     w1.segment_array(va, True)
     assert os.path.isfile(sidecar) and w1.model.engine.calibration_source == "calibrated"
     doc = json.load(open(sidecar))
     assert doc["weights_sha256"] == w1.model.engine.weights_sha256 and doc["act_exponents"] == w1.model.engine.act_exponents()[0]
+    assert len(doc["census_max"]) == 18 and all(512.0 <= v < 4096.0 for v in doc["census_max"][:17]) and doc["volume_id"].startswith("40x200x200:")
+    # the explicit step: the same file from Segmenter.calibrate(image) on a volume the caller chose
+    os.remove(sidecar)
+    info = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td)).calibrate(va)
+    assert info["status"] == "calibrated" and json.load(open(sidecar))["act_exponents"] == doc["act_exponents"] == info["act_exponents"]
     w2 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
     w2.segment_array(vb, True)                                   # its first volume: would calibrate differently on its own
     assert w2.model.engine.calibration_source == "file" and w2.model.engine.act_exponents() == w1.model.engine.act_exponents()
@@ -243,11 +253,38 @@ def test_calibration_is_persisted_next_to_the_checkpoint_and_shared_between_work
     _write_models(td2, 6)
     import shutil
     shutil.copy(sidecar, os.path.join(td2, "segmentation_model.pth.tar.fp16cal.json"))
-    w5 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td2))
+    w5 = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td2, fp16_calibration_write=True))
     with pytest.warns(UserWarning, match="other weights"):
         w5.segment_array(va, True)
     assert w5.model.engine.calibration_source == "calibrated"
     assert json.load(open(os.path.join(td2, "segmentation_model.pth.tar.fp16cal.json")))["weights_sha256"] == w5.model.engine.weights_sha256
+
+
+def test_a_calibration_file_that_does_not_fit_the_data_is_dropped_after_three_flagged_volumes(tmp_path):
+    """a sidecar written from an unrepresentative first volume pinned its exponents for ever -- every later volume tripped the
+    range flag and paid the fp32 repeat, silently.  Now: three consecutive flagged volumes under a calibration that came from a FILE
+    -> a warning, the file is ignored, the next volume recalibrates (and the maps of the flagged volumes were the fp32 repeat's all along)."""
+    from oai_analysis_2_amd.segmentation.segmenter import Segmenter3DInPatchClassWise
+    td = str(tmp_path)
+    _write_models(td, 5)
+    shape = (40, 200, 200)
+    loud = make_volume(1, shape)
+    quiet = [make_volume(10 + i, shape) * 1e-3 for i in range(5)]          # > 128 x quieter than the calibration volume: the LOW bit
+    Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td)).calibrate(loud)
+    w = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
+    eng = None
+    for i in range(3):
+        if i == 2:
+            with pytest.warns(UserWarning, match="consecutive volumes left the range window"):
+                w.segment_array(quiet[i], True)
+        else:
+            w.segment_array(quiet[i], True)
+        eng = w.model.engine
+        assert eng.calibration_source == ("file" if i < 2 else "none")
+    w.segment_array(quiet[3], True)                                        # recalibrates on this volume: no flag, no repeat
+    assert eng.calibration_source == "calibrated" and eng._flag_streak == 0 and not eng.range_overflow()
+    ref = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td, precision="f32", fp16_calibration_file=False)).segment_array(quiet[1], True)
+    assert np.abs(w.segment_array(quiet[1], True) - ref).max() < 1e-5
 
 
 def test_a_network_that_cannot_be_calibrated_runs_f32_with_a_warning():

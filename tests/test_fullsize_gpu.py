@@ -44,15 +44,22 @@ def _reference_noise(golden_dir, case):
 def _compare_with_golden(z, vol, prob, mask, tag, golden_dir, case):
     """prob [2,D,H,W] float32 numpy, mask [2,D,H,W] bool numpy against one segment_fullsize*.npz.
 
-    Budgets: the reference accepts sum|dp| < 12 per 23.6 M voxels against maps stored from another machine (test/test_all.py:32-33) --
-    an absolute number, set for the released network.  Here: max(12, 3 x the reference's OWN fp32-vs-fp64 distance on this network),
-    and pointwise max(1e-5, 8 x its largest fp32-vs-fp64 difference) -- on the base and the windowed case that IS 12 and 1e-5.
-    And directly against the float64 run of the reference's network on six tiles: the GPU path may be at most 2.5 x (fp16x3; measured
-    1.74-1.98 x on all four cases) or 4 x (the exact-fp32-product kernel, whose MFMA accumulates K two products at a time: measured
-    2.86-3.47 x) as far from the truth as the reference's own fp32 run is -- the headline arithmetic is the MORE accurate of the two."""
+    Budgets (round 5: pulled back after VERDICT / ADVICE r4).  The reference accepts sum|dp| < 12 per 23.6 M voxels against maps stored from
+    another machine (test/test_all.py:32-33) -- an absolute number, set for the released network -- and that, with max|dp| < 1e-5 and at most
+    64 flips, is the gate for
+      * the exact-fp32 path (f32) on ALL four cases: with its two-level accumulation (conv3_igemm_f32, round 5) it sits 0.8 x the
+        reference's own distance from the float64 truth (it was 2.9-3.5 x with one running sum) and 0.5-8.4 from the reference;
+      * the headline arithmetic (fp16x3) on the base and the windowed case.
+    On the BN network and the DC-heavy network the reference's OWN fp32 run is 6.5 / 9.1 and 0.6 / 7.4 away from its float64 run: there
+    fp16x3 is gated at max(12, 2 x that noise) and pointwise at max(1e-5, 8 x the reference's largest fp32-vs-fp64 difference); it
+    measures 10.4 / 14.3 (bn) and 0.9 / 11.5 (dc) -- bn-TC is the one figure above the absolute 12, reported as such by bench.py
+    (`parity_headline.abs12`).  Directly against the float64 run of the reference's network on six tiles: f32 at most 1.2 x, fp16x3 at
+    most 2.2 x the reference's own fp32 distance (measured 0.80-0.83 and 1.72-1.95)."""
     assert hashlib.sha256(vol.tobytes()).digest() == bytes(z["volume_sha256"]), "the GPU box regenerated a different input volume"
     noise, noise_max, t_tiles, truth, ref32 = _reference_noise(golden_dir, case)
-    point_tol = max(1e-5, 8.0 * noise_max)
+    f32 = tag.endswith("f32")
+    scaled_case = (not f32) and case in ("bn", "dc")
+    point_tol = max(1e-5, 8.0 * noise_max) if scaled_case else 1e-5
     n = prob[0].size
     sl = tuple(slice(int(a), None, int(st)) for a, st in zip(z["start"], z["stride"]))
     sums = []
@@ -61,9 +68,9 @@ def _compare_with_golden(z, vol, prob, mask, tag, golden_dir, case):
         d = np.abs(prob[c][sl].astype(np.float64) - ref_s)
         scaled = d.sum() * (n / ref_s.size)
         sums.append(scaled)
-        budget = max(12.0, 3.0 * float(noise[c]))
+        budget = max(12.0, 2.0 * float(noise[c])) if scaled_case else 12.0
         print(f"[fullsize {tag}] class {c}: sum|dp| scaled to 23.6M voxels = {scaled:.3f} (budget {budget:.1f}; the reference's own fp32 noise "
-              f"{noise[c]:.2f}), max|dp| = {d.max():.2e} (tolerance {point_tol:.1e})")
+              f"{noise[c]:.2f}; within the reference's absolute 12: {scaled < 12.0}), max|dp| = {d.max():.2e} (tolerance {point_tol:.1e})")
         assert scaled < budget and d.max() < point_tol
         assert abs(prob[c].astype(np.float64).sum() - float(z["prob_sum"][c])) < budget       # all voxels, not only the sample
     # against the reference network's float64 run on the six truth tiles (kept-centre voxels z = 1, y = 2, x = 3 mod 4)
@@ -73,7 +80,7 @@ def _compare_with_golden(z, vol, prob, mask, tag, golden_dir, case):
     e_ref = np.abs(ref32 - truth).sum(axis=(0, 2, 3, 4))
     print(f"[fullsize {tag}] distance from the reference network's float64 run on 6 tiles, GPU / reference-fp32: "
           f"{e_gpu[0] / e_ref[0]:.2f} (FC)  {e_gpu[1] / e_ref[1]:.2f} (TC)")
-    assert (e_gpu <= (4.0 if tag.endswith("f32") else 2.5) * e_ref).all()
+    assert (e_gpu <= (1.2 if f32 else 2.2) * e_ref).all()
     ref_mask = np.stack([np.unpackbits(z["fc_mask_bits"])[:n], np.unpackbits(z["tc_mask_bits"])[:n]]).astype(bool).reshape(2, *SHAPE)
     flips = np.flatnonzero((mask != ref_mask).ravel())
     near = dict(zip(z["near_idx"].tolist(), z["near_prob"].tolist()))
@@ -82,7 +89,7 @@ def _compare_with_golden(z, vol, prob, mask, tag, golden_dir, case):
           f"({int(ref_mask[0].sum())} FC / {int(ref_mask[1].sum())} TC voxels set; {len(near)} voxels within 1e-4 of 0.5); "
           f"max |p_ref - 0.5| at a flip = {max(dist_, default=0.0):.2e}")
     assert all(d < point_tol for d in dist_)
-    assert len(flips) <= 128                                             # (of 47 M; every one of them within point_tol of p = 0.5 -- the line above is the gate)
+    assert len(flips) <= 64                                              # (of 47 M; every one of them within point_tol of p = 0.5 -- the line above is the gate)
     return len(flips), sums
 
 
@@ -96,6 +103,36 @@ def test_full_volume_matches_reference_golden(full, golden_dir):
     eng, v = full["eng"], full["v"]
     mask = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=1, crop_zyx=CROP), SHAPE, TILE, OVL, CROP).cpu().numpy() > 0.5
     _compare_with_golden(z, full["vol"], full["prob"].cpu().numpy(), mask, full["precision"], golden_dir, "base")
+
+
+def test_exact_fp32_path_is_no_noisier_than_the_headline(golden_dir):
+    """the fp32 path is what every range-flag repeat falls back to -- it must not be the noisier one.  Same volume, both
+    arithmetics: the f32 sum|dp| against the reference's run is at most the fp16x3 figure, per class (measured 1.9 / 1.3 vs 3.1 / 2.4)."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    z = np.load(os.path.join(golden_dir, "segment_fullsize.npz"))
+    v = torch.from_numpy(make_volume(42, SHAPE)).cuda()
+    sl = tuple(slice(int(a), None, int(st)) for a, st in zip(z["start"], z["stride"]))
+    sums = {}
+    for precision in ("f32", "fp16x3"):
+        eng = UNetEngine(make_unet_state_dict(0), precision=precision)
+        prob = eng.stitch(eng.segment_tiles(v, TILE, OVL, out_mode=0, crop_zyx=CROP), SHAPE, TILE, OVL, CROP).cpu().numpy()
+        sums[precision] = [np.abs(prob[c][sl].astype(np.float64) - z[k].astype(np.float64)).sum() for c, k in enumerate(("fc_prob_s", "tc_prob_s"))]
+        eng._ws = None
+        del eng
+        torch.cuda.empty_cache()
+    print(f"[fullsize] sum|dp| on the sample, f32 {sums['f32']} vs fp16x3 {sums['fp16x3']}")
+    assert all(a <= b for a, b in zip(sums["f32"], sums["fp16x3"]))
+
+
+def test_host_tile_costs_equal_the_library(full):
+    """parallel.tile_costs_host (planning a tile shard without a device handle: bench.py --dry-run, the world-8 CPU test) is the mirror of
+    oai_unet_tile_costs."""
+    from oai_analysis_2_amd.parallel import tile_costs_host
+    lib_costs = full["eng"].tile_costs(SHAPE, TILE, OVL, CROP)
+    host = tile_costs_host(SHAPE, TILE, OVL, CROP)
+    assert len(host) == len(lib_costs) == 160 and all(abs(a - b) <= 1e-9 * b for a, b in zip(host, lib_costs))
+    untrimmed = tile_costs_host(SHAPE, TILE, OVL, None)
+    assert all(abs(a - b) <= 1e-9 * b for a, b in zip(untrimmed, full["eng"].tile_costs(SHAPE, TILE, OVL, None)))
 
 
 @pytest.mark.parametrize("precision", ["f32", "fp16x3"])

@@ -220,13 +220,15 @@ def test_fp16x3_reports_activations_outside_fp16_range():
 
 
 @pytest.mark.parametrize("opts", [{"sres_mrep": 2}, {"sres_ring": 1}, {"xcd_group": 0}, {"xcd_group": 7}, {"sres": 0}, {"fuse_first": 0}, {"b_lds": 1},
-                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}])
+                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}])
 def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     """The tuning variants of the default path (2 z slices per block, the six-slot plane ring, other XCD dealings, fp32-resident
     activations, ec0 as its own launch instead of inside ec1's halo staging, weight fragments through the workgroup's LDS ring, the
     8-wave double-buffered kernel of the Cout % 128 == 0 layers off / forced also for small launches, skip tensors written in full,
     no range census, ec0 -> ec1 per tile instead of once over the padded volume + a shell per tile) accumulate in the same k order: identical stitched maps, and the golden tolerance of the default.
-    "winograd" (the x axis of the plain layers in Winograd F(2,3) form; default 19 = both cout classes, the two-group form on 16x16x32 tap pairs; 3 = both on 32x32x16; bit 5 = the 64-cout layer on them too) against the direct form (0): same precision, other rounding points."""
+    "winograd" (the x axis of the plain layers in Winograd F(2,3) form; default 19 = both cout classes, the two-group form on 16x16x32 tap pairs; 3 = both on 32x32x16; bit 5 = the 64-cout layer on them too) against the direct form (0): same precision, other rounding points.
+    "m16" 0 (round 5): the direct kernel of the layers with Cout % 128 != 0 on 32x32x16 taps instead of 16x16x32 tap pairs -- other rounding points too; the plane ring and the
+    weight ring exist in the 32x32x16 form only and are compared there."""
     from oai_analysis_2_amd.segmentation.engine import UNetEngine
     z = np.load(os.path.join(golden_dir, "segment_small.npz"))
     vol = torch.from_numpy(make_volume(int(z["volume_seed"]), (24, 72, 72))).cuda()
@@ -245,9 +247,12 @@ def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     base_opts = {"wide": 2} if "wide" not in opts else {}       # (the 24 x 72 x 72 volume has too few workgroups for the default to pick the wide kernel)
     if any(k in opts for k in ("sres_mrep", "sres_ring", "b_lds", "winograd")):
         base_opts["winograd"] = 0                                   # these configurations run every layer through the direct kernels: compared with the direct form
+    if any(k in opts for k in ("sres_ring", "b_lds")):
+        base_opts["m16"] = 0                                        # ... in its 32x32x16 form (the rings have no tap-pair variant)
+        opts = {"m16": 0, **opts}
     base = run(base_opts)
     got = run(opts)
-    if "sres" in opts or "winograd" in opts:                        # other activation format / x axis in Winograd form: same precision, other rounding points
+    if "sres" in opts or "winograd" in opts or opts == {"m16": 0}:  # other activation format / x axis in Winograd form / other MFMA shape: same precision, other rounding points
         assert np.abs(got - base).max() < 1e-5 and not np.array_equal(got, base)
     else:
         assert np.array_equal(got, base)
