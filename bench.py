@@ -383,7 +383,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning option of the fp16x3 path (oai_unet_set_option, include/oai_hip.h); bit-preserving: sres, sres_mrep, sres_ring, "
                          "xcd_group, fuse_first, b_lds, wide, shared_enc, dead_stores, census; NOT bit-preserving: winograd (bit mask, default 19; "
-                         "0 = direct form), winograd_layers; repeatable")
+                         "0 = direct form), winograd_layers, m16 (default 1: tap pairs in the direct kernel), m16_layers; repeatable")
     ap.add_argument("--no-overlap", action="store_true", help="registration after, not underneath, the segmentation (A/B of VolumePipeline.overlap_registration)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of launcher + collectives, no GPU, no kernels")
     args = ap.parse_args()

@@ -149,12 +149,22 @@ typedef struct oai_layer_params {
 int oai_unet_create(const oai_layer_params layers_host[OAI_UNET_NUM_LAYERS], float bn_eps, oai_unet** out);
 void oai_unet_destroy(oai_unet* h);
 
-/* Arithmetic of the 3x3x3 conv layers (everything else is always fp32):
- *   OAI_PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products, the default.
+/* Arithmetic of the 3x3x3 conv layers and the k2s2 up-convs (ec0, the head and everything outside the U-Net are always fp32).  A handle
+ * starts in OAI_PREC_F32; the Python surface (Segmenter3DInPatchClassWise, bench.py) selects OAI_PREC_FP16X3 by default and falls back to
+ * OAI_PREC_F32 per volume when the range flag is raised:
+ *   OAI_PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products; the accumulation is TWO-LEVEL (round 5): one fresh accumulator set per
+ *                    8-channel chunk (108 MFMAs), folded into the running sum by one fp32 add -- 0.8 x the reference's own distance from its
+ *                    float64 run on four reference networks (one running sum over K = 27 Cin: 2.9-3.5 x).  Activations fp32 in memory.
  *   OAI_PREC_BF16X6  every fp32 operand split into 3 bf16 terms, 6 bf16 MFMA passes per product: fp32-grade
- *                    results (dropped terms are O(2^-24)) at 2.7x the fp32 MFMA rate.
- *   OAI_PREC_BF16X3  2 terms, 3 passes: ~2^-17 relative error per product, 5.3x the fp32 MFMA rate.
- * Activations stay fp32 in memory in every mode. */
+ *                    results (dropped terms are O(2^-24)) at 2.7x the fp32 MFMA rate.  Activations fp32 in memory, split while staging.
+ *   OAI_PREC_BF16X3  2 terms, 3 passes: ~2^-17 relative error per product, 5.3x the fp32 MFMA rate.  Activations fp32 in memory.
+ *   OAI_PREC_FP16X3  (below) activations live in memory AS their two fp16 terms ("format S", 4 bytes per element like fp32: unet_sres.h),
+ *                    scaled per layer by a power of two (oai_unet_calibrate_step); fp32 in and out of every entry point.
+ * Collectives: there is no oai_comm_* / oai_zslab_* entry point (SURVEY.md 8b lists them as candidates) BY DESIGN -- the multi-GPU
+ * exchange steps (volume broadcast, all_gather of kept-centre blocks, z-slab gather, the 76-byte range state) are torch.distributed
+ * calls over RCCL on device tensors in oai_analysis_2_amd/parallel.py: host orchestration stays in Python (BASELINE.json north_star),
+ * and this library only provides what those steps need on either side (oai_segment_tiles' tile ranges, oai_stitch_blocks_ranged,
+ * oai_resample_maps_through_phi's z ranges, oai_unet_range_state_snapshot). */
 #define OAI_PREC_F32 0
 #define OAI_PREC_BF16X3 1
 #define OAI_PREC_BF16X6 2
@@ -199,7 +209,7 @@ int oai_unet_census(oai_unet* h, float max_out[OAI_UNET_NUM_LAYERS], int reset, 
 int oai_unet_calibrate_step(oai_unet* h, void* stream, int* more);
 int oai_unet_get_act_exponents(const oai_unet* h, int e_out[OAI_UNET_NUM_LAYERS], int* calibrated);
 int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
-/* Tuning options of the OAI_PREC_FP16X3 path (bit-preserving -- same k order, identical maps -- except "winograd" / "winograd_layers"), by name
+/* Tuning options of the OAI_PREC_FP16X3 path (bit-preserving -- same k order, identical maps -- except "winograd" / "winograd_layers" / "m16" / "m16_layers"), by name
  * (the library does not read the environment):
  *   "sres" 0|1 (1)      activations resident as fp16 term pairs (unet_sres.h) / fp32-resident split kernels
  *   "sres_mrep" 2|4 (4) z slices per workgroup of the split-resident conv kernel
@@ -219,6 +229,12 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *                       ~13 % higher at the power wall; another summation order, same gates); bit 5: the same for the 64-cout layer, all its launch shapes
  *                       (measured within noise of bit 4 alone: not in the default).  A value depends on the parity of its voxel's x only -- not on blocks, strips
  *                       or batching.  "winograd_layers" (mask, all): bit k = layer k may take it (A/B of single layers)
+ *   "m16" 0|1 (1)       NOT bit-preserving (round 5): the direct kernel conv3_igemm_sres -- ec1 with the fused ec0, ec2, dc1 with the fused head, and any
+ *                       layer "winograd" leaves to it -- runs its taps on v_mfma_f32_16x16x32_f16 with K = a PAIR of taps (27 = 13 pairs + 1) for every
+ *                       layer with Cout % 128 != 0 (a layer that may take the bit-identical 128-cout form conv3_igemm_sres2 keeps 32x32x16, so "wide"
+ *                       stays bit-preserving); every launch shape of the kernel has the variant: one summation order per layer.  Same cycles per FLOP,
+ *                       +12-14 % clock at the power wall: ec1 16.8 -> 14.6, ec2 4.9 -> 3.9, dc1 8.5 -> 7.2 ms per 160 tiles.  "m16_layers" (mask, all):
+ *                       bit k = layer k may take it (A/B of single layers)
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)
  * Unknown names and out-of-range values return OAI_ERR_ARG. */

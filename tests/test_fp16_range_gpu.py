@@ -268,8 +268,8 @@ def test_a_calibration_file_that_does_not_fit_the_data_is_dropped_after_three_fl
     td = str(tmp_path)
     _write_models(td, 5)
     shape = (40, 200, 200)
-    loud = make_volume(1, shape)
-    quiet = [make_volume(10 + i, shape) * 1e-3 for i in range(5)]          # > 128 x quieter than the calibration volume: the LOW bit
+    loud = make_volume(1, shape)                                           # the unrepresentative first volume (the names are historical: `quiet` is the cohort)
+    quiet = [make_volume(10 + i, shape) * 200.0 for i in range(5)]         # the cohort: 200 x louder -- beyond 65504 under exponents chosen for `loud` (overflow bit)
     Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td)).calibrate(loud)
     w = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
     eng = None
@@ -284,7 +284,8 @@ def test_a_calibration_file_that_does_not_fit_the_data_is_dropped_after_three_fl
     w.segment_array(quiet[3], True)                                        # recalibrates on this volume: no flag, no repeat
     assert eng.calibration_source == "calibrated" and eng._flag_streak == 0 and not eng.range_overflow()
     ref = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td, precision="f32", fp16_calibration_file=False)).segment_array(quiet[1], True)
-    assert np.abs(w.segment_array(quiet[1], True) - ref).max() < 1e-5
+    # (200 x the usual input: logits of several hundred, so a 1e-6 relative logit difference is ~1e-4 of probability on the sigmoid's flank)
+    assert np.abs(w.segment_array(quiet[1], True) - ref).max() < 1e-3
 
 
 def test_a_network_that_cannot_be_calibrated_runs_f32_with_a_warning():
