@@ -50,6 +50,14 @@ int oai_device_info(char* name, int cap);
 int oai_grid_sample3d(const float* src_dev, int C, int d, int h, int w,
                       const float* coords_dev, int D, int H, int W, float* out_dev, void* stream);
 
+/* Process-wide tuning options of the warp kernels (bit-preserving; the library does not read the environment):
+ *   "brick" 0|1 (0)  oai_grid_sample3d / oai_compose (C = 1 or 3) through sample_brick_kernel: a block owns a 16 x 8 x 4 output brick and, when the
+ *                    bounding box of the brick's corners fits 24 KB, stages that box of the source in LDS by LDS-DMA and takes the corners
+ *                    from there (the gather form is bound by the CU's L1 tag pipeline: profiles/r02_registration.md); bricks whose box does
+ *                    not fit gather from memory as before.  Same arithmetic in the same order: bit-identical outputs.  Replaces the same
+ *                    reference op, mermaidlite.compute_warped_image_multiNC as reached from oai_analysis/registration.py:25. */
+int oai_warp_set_option(const char* name, int value);
+
 /* out = coords + sample(disp, coords): FunctionFromVectorField's transform(coords).
  * coords_dev == NULL means the identity map (the "sampled" path at another resolution);
  * if additionally (d,h,w)==(D,H,W) and shortcut != 0, out = identity + disp exactly

@@ -82,6 +82,7 @@ SIGNATURES = {
     "oai_unet_forward_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "oai_segment_tiles": (_I, [_P, _P, _I, _I, _I, _I3, _I3, _I3, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "oai_unet_volume_flops": (_D, [_P, _I, _I, _I, _I3, _I3, _I3, _I, _I]),
+    "oai_warp_set_option": (_I, [C.c_char_p, _I]),
     "oai_stitch_blocks": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _I3, _P, _P]),
     "oai_stitch_blocks_ranged": (_I, [_P, _I, _I, _I, _I, _I3, _I3, _I3, _P, _I, _I, _P, _P]),
     "oai_unet_tile_flops": (_D, [_P, _I, _I, _I, _I3, _I]),

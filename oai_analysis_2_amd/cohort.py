@@ -33,13 +33,25 @@ class CohortRunner:
     """Four things overlap per volume: the compute of volume i (main stream, launch thread), the host staging + H2D of volume i+1
     (upload worker, copy stream), the D2H of volume i-1's results (copy stream) and the host copy of volume i-2's results out of
     the pinned buffers into memory the caller owns (download worker).  The launch thread never copies and never waits for a copy
-    that is not at least one volume old.  ``stats`` accumulates what the workers moved (bytes, seconds) for bench.py."""
+    that is not at least ``LAG`` volumes old.  ``stats`` accumulates what the workers moved (bytes, seconds) for bench.py."""
 
-    N_OUT_SETS = 2                 # pinned result sets: one being filled by the D2H of volume i-1 while the worker empties the other
+    # Results are handed out `LAG` volumes behind the compute being queued.  Measured (scripts/bench_cohort.py, GPU-side stamps): the D2H of a
+    # volume's 566 MB runs UNDERNEATH the next volume's kernels and then takes ~100 ms, not the 12 ms of an idle PCIe link -- with a lag of one
+    # volume the launch thread waited for it and queued the next volume ~4 ms late (0.947 of the resident rate); with two it never waits.
+    LAG = 2
+    N_OUT_SETS = LAG + 1           # pinned result sets: one per volume whose download may be in flight or being emptied
 
-    def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False):
+    def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False, high_priority_compute: bool = False):
         self.pipe = pipeline
         self.keep_on_device = keep_on_device
+        # What is left between the streamed and the resident rate (2-3 %): the runtime executes a D2H into pinned memory as a copy KERNEL on the
+        # compute units (`__amd_rocclr_copyBuffer` in the kernel trace of scripts/trace_cohort.py; the memory-copy trace holds no D2H entry), 7 ms
+        # per volume underneath the next volume's first kernels.  `high_priority_compute` queues the volumes' kernels on a high-priority stream
+        # of the runner's own so that the copy kernels yield -- measured 142.1 -> 136.2 ms per volume in one arrangement and 137 -> 142 in
+        # another (the ICON side stream's priority decides), so it is an experiment switch, NOT the default; and it takes the engines off the
+        # caller's stream: a consumer that uses the same pipeline between two results must then synchronise with the runner itself.
+        dev_ = pipeline.unet.device
+        self.compute_stream = torch.cuda.Stream(device=dev_, priority=torch.cuda.Stream.priority_range()[1]) if high_priority_compute else None
         self.copy_stream = torch.cuda.Stream(device=pipeline.unet.device)      # uploads (and the lazy normalisation of the next volume)
         # downloads on a stream of their own: the D2H of volume i is queued right behind its compute and waits for it (~140 ms); on the
         # upload stream it would hold the H2D of volume i+2 back behind that wait (PCIe is full duplex: the two directions do not compete)
@@ -55,7 +67,10 @@ class CohortRunner:
         self._clone = ThreadPoolExecutor(max_workers=5, thread_name_prefix="oai-clone")      # a volume's five result tensors are copied out side by side (one core
         #                                                                                      does ~5-10 GB/s into freshly faulted pages: 566 MB would take most of a volume's compute time)
         self._lock = threading.Lock()
-        self.stats = {"stage_bytes": 0, "stage_s": 0.0, "clone_bytes": 0, "clone_s": 0.0, "launch_wait_s": 0.0}
+        # what the workers moved, and where the LAUNCH thread spent its time: waiting for an upload, queueing a volume's kernels, issuing its D2H,
+        # waiting for a finished result (bench.py: streamed_from_host)
+        self.stats = {"stage_bytes": 0, "stage_s": 0.0, "clone_bytes": 0, "clone_s": 0.0, "launch_wait_s": 0.0,
+                      "t_upload_wait": 0.0, "t_queue_compute": 0.0, "t_issue_d2h": 0.0, "t_result_wait": 0.0}
 
     def close(self) -> None:
         self._up.shutdown(wait=True)
@@ -110,17 +125,19 @@ class CohortRunner:
                 key = (name, tuple(t.shape), t.dtype)
                 if key not in pins:
                     pins[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-                pins[key].copy_(t, non_blocking=True)
-                t.record_stream(self.down_stream)
+                pins[key].copy_(t, non_blocking=True)             # (no record_stream: the download worker holds `res` until this copy has completed --
+                #                                                    the allocator gets the blocks back by plain refcount, without per-allocation event polling)
             ev = torch.cuda.Event()
             ev.record(self.down_stream)
         return k, ev, tuple((name, tuple(getattr(res, name).shape), getattr(res, name).dtype) for name in names)
 
-    def _collect(self, k: int, ev: torch.cuda.Event, keys: tuple, repeated: bool) -> Optional[VolumeResult]:
+    def _collect(self, k: int, ev: torch.cuda.Event, keys: tuple, repeated: bool, held=None) -> Optional[VolumeResult]:
         """Download worker: wait for the D2H, copy the results out of the pinned set into memory the caller owns, free the set.  None = the
-        fp16 range flag of the volume (4 bytes, rides along) is raised: the results must not be used."""
+        fp16 range flag of the volume (4 bytes, rides along) is raised: the results must not be used.  ``held``: the device tensors being
+        copied -- referenced until the copy is done."""
         try:
             ev.synchronize()
+            held = None                                                # the device results may go back to the allocator now
             pins = self._pin_out[k]
             if len(keys) > 5 and int(pins[keys[5]][0]):
                 return None
@@ -136,28 +153,33 @@ class CohortRunner:
 
     def _download_async(self, res: VolumeResult, done: torch.cuda.Event) -> Future:
         k, ev, keys = self._queue_d2h(res, done)
-        return self._down.submit(self._collect, k, ev, keys, res.repeated_f32)
+        return self._down.submit(self._collect, k, ev, keys, res.repeated_f32, res)
 
     def _finish(self, pending) -> VolumeResult:
         """Results of a queued volume whose download was started a volume ago; a volume whose fp16x3 segmentation left fp16's range is
         repeated in exact fp32 here (the check is lazy -- at download time -- so the overlap of the normal case is kept; never silent)."""
         i, res, done, dev, img, fut = pending
+        cs = self.compute_stream if self.compute_stream is not None else torch.cuda.current_stream(self.pipe.unet.device)
         if self.keep_on_device:
             done.synchronize()
             if res.overflow is not None:
                 raised = bool(int(res.overflow.item()))
                 self.pipe.unet.note_volume_flag(raised)
                 if raised:
-                    res = self.pipe.rerun_f32(dev, img)
-                    torch.cuda.current_stream().synchronize()
+                    with torch.cuda.stream(cs):
+                        res = self.pipe.rerun_f32(dev, img)
+                    cs.synchronize()
+            for name in _RESULT_NAMES:                                    # produced on the runner's compute stream, handed to the caller's
+                getattr(res, name).record_stream(torch.cuda.current_stream(self.pipe.unet.device))
             return res
         out = fut.result()
         if res.overflow is not None:
             self.pipe.unet.note_volume_flag(out is None)
         if out is None:
-            res = self.pipe.rerun_f32(dev, img)
-            done = torch.cuda.Event()
-            done.record()
+            with torch.cuda.stream(cs):
+                res = self.pipe.rerun_f32(dev, img)
+                done = torch.cuda.Event()
+                done.record(cs)
             out = self._download_async(res, done).result()
         return out
 
@@ -165,7 +187,7 @@ class CohortRunner:
         """Yield (index, result) for the volumes this worker processes, in its processing order.  ``queue`` (a
         ``parallel.VolumeQueue`` shared by all ranks) assigns volumes dynamically -- the worker claims one volume ahead, so that its
         upload overlaps the current compute; without a queue the static split index % world == rank is used.  Results are yielded
-        ONE volume behind their compute's queueing (their host copy runs on the download worker meanwhile)."""
+        ``LAG`` volumes behind their compute's queueing (their download and host copy run on the workers meanwhile)."""
         if queue is not None:
             order = iter(queue)
         else:
@@ -178,21 +200,34 @@ class CohortRunner:
         nxt = self._up.submit(self._upload, lambda i=cur: images[i], 0)
         waiting: deque = deque()                                          # volumes whose compute is queued: (index, res, done, dev, img, download future | None)
         k = 0
+        st, clock = self.stats, time.perf_counter
+        caller = torch.cuda.current_stream(self.pipe.unet.device)
+        cs = self.compute_stream if self.compute_stream is not None else caller
+        cs.wait_stream(caller)                                            # whatever the caller queued before (engines, atlas) is visible to the volumes' kernels
         while cur is not None:
+            t0 = clock()
             dev, ev, img = nxt.result()
-            torch.cuda.current_stream().wait_event(ev)
-            dev.record_stream(torch.cuda.current_stream())                # allocated on the copy stream, read by the compute stream
-            res = self.pipe.run(dev, img, check=False)                    # queued, not waited for; the range flag is read at download time
-            done = torch.cuda.Event()
-            done.record()
+            t1 = clock()
+            with torch.cuda.stream(cs):
+                cs.wait_event(ev)
+                dev.record_stream(cs)                                     # allocated on the copy stream, read by the compute stream
+                res = self.pipe.run(dev, img, check=False)                # queued, not waited for; the range flag is read at download time
+                done = torch.cuda.Event()
+                done.record(cs)
+            t2 = clock()
             following = next(order, None)                                 # claimed now: its host staging + H2D run behind this volume's compute
             if following is not None:
                 nxt = self._up.submit(self._upload, lambda i=following: images[i], (k + 1) & 1)
             fut = None if self.keep_on_device else self._download_async(res, done)      # D2H queued behind `done`; the host copy on the worker
+            t3 = clock()
             waiting.append((cur, res, done, dev, img, fut))
-            while len(waiting) > 1:                                       # hand out what is at least one volume old
+            st["t_upload_wait"] += t1 - t0; st["t_queue_compute"] += t2 - t1; st["t_issue_d2h"] += t3 - t2
+            while len(waiting) > self.LAG:                                # hand out what is at least LAG volumes old
                 p = waiting.popleft()
-                yield p[0], self._finish(p)
+                t4 = clock()
+                out = self._finish(p)
+                st["t_result_wait"] += clock() - t4
+                yield p[0], out
             cur, k = following, k + 1
         while waiting:
             p = waiting.popleft()

@@ -348,7 +348,12 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     constexpr int D = WS ? 2 : 1, NB = D + 1;
     f32x4 bq[NB][2][NREP];                                          // [tap % NB][term][n]
     f32x4 bXlo[2], bXhi[2], bY[4];                                  // M16: X' (the high terms b0), couts n 0, 1 and n 2, 3, and Y' (the low terms b1) of the running step
-    if (M16 && !stager) {                                           // (WS: the multipliers only)
+    if (M16 && !WS) {
+        // (round 5) the fragments of a chunk's step 0 are requested at the chunk's top, in front of the transform: see run_chunks
+        sgpr_settle(wp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first raw box has landed
+        zero_missing();
+    } else if (M16 && !stager) {                                    // (WS: the multipliers only)
         sgpr_settle(wp);
 #pragma unroll
         for (int n = 0; n < 2; ++n) { bXlo[n] = n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane); bXhi[n] = n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane); }
@@ -357,7 +362,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         wp += STEP * 16;
         vm_wait<0>(bXlo[0], bXlo[1], bXhi[0], bXhi[1]);
         vm_wait<0>(bY[0], bY[1], bY[2], bY[3]);
-        if constexpr (!WS) zero_missing();                          // (the first raw box has landed with them)
     } else if (!stager) {
         sgpr_settle(wp);                                            // wp has just been made uniform by v_readfirstlane
 #pragma unroll
@@ -389,6 +393,18 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             // (same instructions, L1-resident: prices the L2 -> L1 leg alone), 131072 every halo piece from the zero record (same DMA
             // instructions, no HBM / L2 traffic behind them); scripts/wino_var.sh, profiles/r03_winograd.md, r04_wino_stream.md)
             if constexpr (!WS) {
+                if constexpr (M16) {
+                    // (round 5) The weight fragments of this chunk's step 0, requested HERE -- they land under the transform (~1 us) -- instead of
+                    // during the previous chunk's last step, where hi(0) was requested 16 MFMAs before the chunk-end wait: every chunk ended with
+                    // an exposed L2 round trip, for all eight waves (the barrier waits for the slowest).  Same basic block as their first use.
+                    if (!OAI_DBG_BIT(a, 4096)) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
+                        bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane);
+                        bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane);
+                    }
+                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+                }
                 if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
                 if constexpr (M16) compute_a16((unsigned)(zp * MREP) * (unsigned)(4 * HY * NP * 64));      // (MS = 2: this wave's slice pair)   behind the transform's register peak, in front of the barrier: under the wait for the slowest wave
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -496,8 +512,10 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
                 };
-                auto np_of = [](int j) constexpr { int c = 0; for (int q = 0; q < NIT; ++q) c += (q % 5 == j) ? 1 : 0; return c; };
-                static_assert(NIT <= 10, "at most two pieces per step (the waits below name 1 or 2)");
+                // pieces of the NEXT chunk's raw box: requested at the ends of steps 0..3 (step 4 requests nothing: what the chunk-end wait covers was
+                // requested at least one step -- 96 MFMAs -- earlier)
+                auto np_of = [](int j) constexpr { int c = 0; for (int q = 0; q < NIT; ++q) c += (j < 4 && q % 4 == j) ? 1 : 0; return c; };
+                static_assert(NIT >= 4 && NIT <= 8, "one or two pieces per step 0..3 (the waits below name 1 or 2)");
                 float4 af[MREP][2];                                     // [m][p]: the A fragments of the running pass
 #pragma unroll
                 for (int m = 0; m < ML; ++m)
@@ -506,9 +524,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     constexpr int kDummy = 0; (void)kDummy;
-                    const int npp = np_of((j + 4) % 5);                 // pieces requested at the end of the previous step
-                    // Y'(j) has landed; younger: lo(j), hi(j), pieces(j - 1)
-                    if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<6>(bY[0], bY[1], bY[2], bY[3]);
+                    // vector-memory operations younger than Y'(j) at the top of step j: lo(j), hi(j) and the pieces requested at the end of step j - 1
+                    const int npp = j > 0 ? np_of(j - 1) : 0;           // (step 0: the fragments were requested at the chunk's top, nothing behind them)
+                    if (npp == 0) vm_wait<4>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<6>(bY[0], bY[1], bY[2], bY[3]);
                     __builtin_amdgcn_sched_barrier(0);
                     // pass B: a0 . Y'  (step 4: [a0 | a1] . [b1 | 0])
 #pragma unroll
@@ -518,13 +536,21 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
 #pragma unroll
                             for (int n = 0; n < 4; ++n) mma(af[m][p], bY[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!OAI_DBG_BIT(a, 4096)) {                        // Y' of the next step (of the next chunk behind step 4)
+                    if (j < 4 && !OAI_DBG_BIT(a, 4096)) {               // Y' of the next step
 #pragma unroll
                         for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
                     }
-                    // lo(j) has landed; younger: hi(j), pieces(j - 1), Y'(j + 1)
-                    if (npp == 1) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
-                    else asm volatile("s_waitcnt vmcnt(8)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                    // lo(j) has landed; younger: hi(j) 2, pieces(j - 1) npp, Y'(j + 1) 4 (steps 0..3)
+                    {
+                        constexpr int kD2 = 0; (void)kD2;
+                        const int y = 2 + npp + (j < 4 ? 4 : 0);
+                        if (y == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        else if (y == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        else if (y == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        else if (y == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        static_assert(true, "");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     // pass A, low couts: a0 . X'[0, 1] over all slices
 #pragma unroll
@@ -535,8 +561,14 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                             for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
                     __builtin_amdgcn_sched_barrier(0);                  // (the wait below must not rise above these MFMAs: they are its lead)
                     // hi(j) has landed; younger: pieces(j - 1), Y'(j + 1)
-                    if (npp == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
-                    else asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                    {
+                        const int y = npp + (j < 4 ? 4 : 0);
+                        if (y == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        else if (y == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        else if (y == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        else if (y == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     // pass A, high couts; behind each slice the a1 fragments of pass C take its registers
 #pragma unroll
@@ -561,13 +593,11 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
 #pragma unroll
                                 for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (!OAI_DBG_BIT(a, 4096)) {                        // the low couts of the next step's X'
-                        bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (j < 4) {
-                        // pass C, high couts; behind each slice the a0 fragments of the next step (same chunk) take its registers
+                        if (!OAI_DBG_BIT(a, 4096)) {                    // the low couts of the next step's X'
+                            bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // pass C, high couts; behind each slice the a0 fragments of the next step take its registers
 #pragma unroll
                         for (int m = 0; m < ML; ++m) {
 #pragma unroll
@@ -579,22 +609,21 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                             for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j < 3 ? (j + 1) * 2 : 8], m, p);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                    }
-                    if (!OAI_DBG_BIT(a, 4096)) {                        // the high couts of the next step's X'
-                        bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane);
-                    }
-                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
-                    if (!OAI_DBG_BIT(a, 32768)) {
+                        if (!OAI_DBG_BIT(a, 4096)) {                    // the high couts of the next step's X'
+                            bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane);
+                        }
+                        if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+                        if (!OAI_DBG_BIT(a, 32768)) {
 #pragma unroll
-                        for (int q = 0; q < NIT; ++q)
-                            if (q % 5 == j) issue_piece_s(q, ch + 1);
+                            for (int q = 0; q < NIT; ++q)
+                                if (q % 4 == j) issue_piece_s(q, ch + 1);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // chunk end: everything has landed -- the next raw box for this thread (the barrier says so for everybody, and that everybody
-                // is done reading T) and the fragments of the next chunk's step 0
-                vm_wait<0>(bXlo[0], bXlo[1], bXhi[0], bXhi[1]);
-                vm_wait<0>(bY[0], bY[1], bY[2], bY[3]);
+                // chunk end: the next raw box has landed for this thread (its last pieces were requested a whole step ago); the barrier says so
+                // for everybody -- and that everybody is done reading T.  No weight fragment is in flight (step 4 requested none).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 zero_missing();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();

@@ -45,6 +45,12 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def warp_set_option(name: str, value: int) -> None:
+    """Process-wide tuning option of the warp kernels (include/oai_hip.h: oai_warp_set_option): "brick" 0|1 -- grid_sample3d / compose through
+    the LDS-staged brick kernel; bit-identical outputs."""
+    _lib.check(_lib.load().oai_warp_set_option(name.encode(), int(value)), "oai_warp_set_option")
+
+
 @_on_tensor_device
 def grid_sample3d(src: torch.Tensor, coords: Optional[torch.Tensor], out_shape: Optional[Sequence[int]] = None) -> torch.Tensor:
     """src [C,d,h,w], coords [3,D,H,W] in [0,1] (None = identity of out_shape) -> [C,D,H,W]."""

@@ -122,8 +122,8 @@ class VolumePipeline:
         """Registration needs only the image, not its segmentation: its small, launch- and latency-bound kernels (a few dozen
         workgroups at the deep ICON levels) run on a side stream underneath the segmentation's MFMA kernels; the resample joins."""
         main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.unet.device)
+        if self._side is None or self._side.priority != main.priority:
+            self._side = torch.cuda.Stream(device=self.unet.device, priority=main.priority)      # (the compute stream's own priority: under a high-priority caller -- CohortRunner -- a default-priority side stream would starve)
         self._side.wait_stream(main)                                    # vol (and the atlas) are ready
         with torch.cuda.stream(self._side):
             phi = self.register(vol)
@@ -164,8 +164,8 @@ class VolumePipeline:
         main = torch.cuda.current_stream()
         phi = None
         if self.overlap_registration:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.unet.device)
+            if self._side is None or self._side.priority != main.priority:
+                self._side = torch.cuda.Stream(device=self.unet.device, priority=main.priority)      # (the compute stream's own priority: under a high-priority caller -- CohortRunner -- a default-priority side stream would starve)
             self._side.wait_stream(main)                                # the broadcast volume is ready
             with torch.cuda.stream(self._side):
                 phi = self.register(vol)

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oai_analysis_2_amd import ops
 from oai_analysis_2_amd.synth import identity_map, make_smooth_field, make_volume
 
+if os.environ.get("BRICK"):        # BRICK=1: the LDS-staged brick form of grid_sample3d / compose (option "brick", round 5)
+    ops.warp_set_option("brick", int(os.environ["BRICK"]))
 N = int(os.environ.get("N", "160"))
 shape = (N, N, N)
 V = N ** 3

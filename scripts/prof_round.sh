@@ -41,7 +41,11 @@ try: traffic_f32()
 except Exception as e: print("f32 traffic:", e)
 f = load(find("fetch", "counter_collection.csv"), "FETCH_SIZE"); w = load(find("write", "counter_collection.csv"), "WRITE_SIZE")
 def warm(rows):                                       # second (warm) 32-tile pass = from its first launch on: ec0, or the ec0-fused ec1 (<..., false, true, false>)
-    first = [k for k, r in enumerate(rows) if "conv3_igemm_sres<" in r["Kernel_Name"] and "false, true, false>" in r["Kernel_Name"]] or \
+    def is_first(name):                                # conv3_igemm_sres<MREP, RX, RY, WY, WX, RING, FIRST, BLDS, M16> with FIRST = true
+        if "conv3_igemm_sres<" not in name: return False
+        a = [x.strip() for x in name.split("conv3_igemm_sres<", 1)[1].split(">", 1)[0].split(",")]
+        return len(a) > 6 and a[6] == "true"
+    first = [k for k, r in enumerate(rows) if is_first(r["Kernel_Name"])] or \
             [k for k, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"]]
     return rows[max(first):]
 f = warm(f); w = warm(w)

@@ -40,6 +40,30 @@ def test_grid_sample_and_compose(shape, src_shape):
     assert _rel(got_c, ref_c) < TOL and np.abs(got_c - ref_c).max() < 2e-6
 
 
+@pytest.mark.parametrize("shape,src_shape,amp", [((24, 40, 36), (24, 40, 36), 0.05), ((17, 33, 29), (9, 17, 15), 0.05), ((160, 160, 160), (160, 160, 160), 0.03),
+                                                 ((40, 50, 70), (40, 50, 70), 0.4)])
+def test_brick_form_is_bit_identical(shape, src_shape, amp):
+    """Option "brick" (round 5): grid_sample3d / compose with the source box of a 16 x 8 x 4 output brick staged in LDS -- same corners, same
+    weights, same order: torch.equal with the gather form, on smooth fields (boxes fit), on a field so rough that most boxes do NOT fit
+    (amplitude 0.4: the per-brick fallback), with coordinates outside [0, 1] (border clamp) and with the identity map (coords None)."""
+    from oai_analysis_2_amd import ops
+    img = _dev(make_volume(3, src_shape)[None])
+    field = _dev(make_smooth_field(4, src_shape, 0.03))
+    coords = (oicon.identity_map(shape)[0].numpy() + make_smooth_field(5, shape, amp)).astype(np.float32)
+    coords[:, :2] -= 0.1
+    coords[:, -2:] += 0.1
+    coords = _dev(coords)
+    try:
+        ops.warp_set_option("brick", 0)
+        want = (ops.grid_sample3d(img, coords), ops.compose(field, coords), ops.grid_sample3d(img, None, out_shape=shape), ops.compose(field, None, out_shape=shape))
+        ops.warp_set_option("brick", 1)
+        got = (ops.grid_sample3d(img, coords), ops.compose(field, coords), ops.grid_sample3d(img, None, out_shape=shape), ops.compose(field, None, out_shape=shape))
+    finally:
+        ops.warp_set_option("brick", 0)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_identity_paths():
     from oai_analysis_2_amd import ops
     shape, low = (20, 48, 44), (10, 24, 22)
