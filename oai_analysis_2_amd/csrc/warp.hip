@@ -138,8 +138,8 @@ sample_kernel(const float* __restrict__ src, int C_rt, int d, int h, int w,
 // sample_kernel is bound by the CU's L1 tag pipeline (TCP_GATE_EN1 97 % of the kernel, 2.35 line accesses per voxel on the spec's +-14-voxel
 // field): every lane's four pair loads are separate tag lookups.  Here a block owns a 16 (x) x 8 (y) x 4 (z) output brick, computes its taps,
 // reduces the bounding box of their corners over the block (DPP wave reductions + 24 words of LDS), and -- when the box fits kBrickCap floats
-// (a per-brick test; on the spec's field a 512-voxel brick's box is ~8 x the brick) -- copies the box's rows into LDS by LDS-DMA (one
-// global_load_lds_dword per row and wave: a row of the box is one or two cache lines, ~3 x fewer tag lookups per voxel than the gathers) and
+// (a per-brick test; on the spec's field a 512-voxel brick's box is ~3.5 x the brick) -- copies the box into LDS by LDS-DMA (the box as one linear
+// list, 64 lanes per global_load_lds_dword: a row of the box is one or two cache lines, ~3 x fewer tag lookups per voxel than the gathers) and
 // takes the eight corners from LDS (ds_read2_b32 pairs), in gather8's order: bit-identical results.  A brick whose box does not fit (a fold, a
 // strong shear) runs gather8 on global memory as before.  Brick 16 x 8 x 4: coordinate / result rows are 64-byte runs, four rows per wave.
 constexpr int kBrickX = 16, kBrickY = 8, kBrickZ = 4;
@@ -237,7 +237,7 @@ sample_brick_kernel(const float* __restrict__ src, int d, int h, int w, const fl
     for (int i = 0; i < 6; ++i) m[i] = max(max(red[0][i], red[1][i]), max(red[2][i], red[3][i]));
     const int xlo = -m[0], ylo = -m[2], zlo = -m[4];
     const int nx = m[1] - xlo + 1, ny = m[3] - ylo + 1, nz = m[5] - zlo + 1;
-    const bool staged = m[1] != kNone && nx <= 64 && nx * ny * nz <= kBrickCap;      // block-uniform
+    const bool staged = m[1] != kNone && nx * ny * nz <= kBrickCap;      // block-uniform
     const int C = CT;
 #pragma unroll 1
     for (int c = 0; c < C; ++c) {
@@ -245,22 +245,28 @@ sample_brick_kernel(const float* __restrict__ src, int d, int h, int w, const fl
         float r[U];
         if (staged) {
             if (c > 0) __syncthreads();                              // the previous channel's box has been read
-            // rows of the box, dealt to the waves: row q = (ez, ey) -> nx floats from src[zlo + ez][ylo + ey][xlo ..] to box[q * nx ..]
+            // the box as ONE linear list of nx * ny * nz floats, element e = it * 256 + tid -> (ez, ey, ex): every LDS-DMA instruction moves 64 lanes
+            // (a first version issued one instruction per box row, ~25 of 64 lanes active, ~170 instructions per brick where the gather form
+            // issues 32: 43.8 us against the gather form's 24.0 -- vector-memory ISSUE, not the tag pipeline, was then the limit)
             {
                 const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)box;
-                const int rows = ny * nz;
-                int ez = 0, ey = wave;
-                while (ey >= ny) { ey -= ny; ++ez; }
-                for (int q = wave; q < rows; q += 4) {
-                    if (lane < nx) {
-                        const float* g = plane + ((zlo + ez) * h + (ylo + ey)) * w + xlo + lane;
-                        const unsigned la = __builtin_amdgcn_readfirstlane(lbase + (unsigned)(q * nx) * 4u);
+                const int vol = nx * ny * nz, nxy = nx * ny;
+                const float inv_nxy = 1.0f / (float)nxy, inv_nx = 1.0f / (float)nx;
+                for (int e0 = 0; e0 < vol; e0 += kThreads) {
+                    const int e = e0 + tid;
+                    int ez = (int)((float)e * inv_nxy);                       // e / nxy for e < 2^13: the float quotient is within 1 of it
+                    int rem = e - ez * nxy;
+                    if (rem < 0) { --ez; rem += nxy; } else if (rem >= nxy) { ++ez; rem -= nxy; }
+                    int ey = (int)((float)rem * inv_nx);
+                    int ex = rem - ey * nx;
+                    if (ex < 0) { --ey; ex += nx; } else if (ex >= nx) { ++ey; ex -= nx; }
+                    if (e < vol) {
+                        const float* g = plane + ((zlo + ez) * h + (ylo + ey)) * w + xlo + ex;
+                        const unsigned la = __builtin_amdgcn_readfirstlane(lbase + (unsigned)(e0 + (tid & ~63)) * 4u);
                         unsigned keep;
                         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                                      : "=&s"(keep) : "v"(g), "s"(la) : "memory");
                     }
-                    ey += 4;
-                    while (ey >= ny) { ey -= ny; ++ez; }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
