@@ -1407,14 +1407,20 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
     float acc[2][COUT];
 #pragma unroll
     for (int j = 0; j < COUT; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
-#pragma unroll 1
+    // all 36 inputs of the voxel pair in flight before the first FMA (round 5): loaded inside the loop below -- it is not unrolled: 864 FMAs per
+    // iteration -- every one of its nine iterations began with an exposed memory round trip (the shell pass of ec0: 2.17 ms for 38 GFLOP)
+    float inr[9][4];
+#pragma unroll
     for (int zy = 0; zy < 9; ++zy) {
-        const int dz = zy / 3, dy = zy - 3 * dz;
-        const int a = dz == 0 ? iz[0] : dz == 1 ? iz[1] : iz[2];
-        const int b = dy == 0 ? iy[0] : dy == 1 ? iy[1] : iy[2];
+        const int a = iz[zy / 3], b = iy[zy % 3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) inr[zy][d] = (a | b | ix[d]) >= 0 ? base[(size_t)a + b + ix[d]] : 0.0f;
+    }
+#pragma unroll
+    for (int zy = 0; zy < 9; ++zy) {
         float in[4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) in[d] = (a | b | ix[d]) >= 0 ? base[(size_t)a + b + ix[d]] : 0.0f;
+        for (int d = 0; d < 4; ++d) in[d] = inr[zy][d];
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const float* w = &wl[(zy * 3 + dx) * COUT];

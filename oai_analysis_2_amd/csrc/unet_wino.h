@@ -337,6 +337,17 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wp_v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp_v));
     const unsigned wlane = lane * 16;
 
+    f32x4 fs[WS && M16 ? 2 : 1][8];                                  // [set][X' n2 0..3 | Y' n2 0..3]
+    auto ws16_request = [&](f32x4 (&d)[8]) __attribute__((always_inline)) {
+        if (!OAI_DBG_BIT(a, 4096)) {
+            d[0] = gload16_asm<0>(wp, wlane); d[1] = gload16_asm<1024>(wp, wlane); d[2] = gload16_asm<2048>(wp, wlane); d[3] = gload16_asm<3072>(wp, wlane);
+            d[4] = gload16_asm<0>(wp + 4096, wlane); d[5] = gload16_asm<1024>(wp + 4096, wlane); d[6] = gload16_asm<2048>(wp + 4096, wlane); d[7] = gload16_asm<3072>(wp + 4096, wlane);
+        }
+        if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+    };
+    auto ws16_landed = [&](f32x4 (&d)[8]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) :: "memory");
+    };
     // ---- prologue: the first raw box and the weight fragments of tap 0 (WS: the stagers also transform chunk 0 and request chunk 1)
     if constexpr (!WS) {
 #pragma unroll
@@ -353,15 +364,12 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         sgpr_settle(wp);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first raw box has landed
         zero_missing();
-    } else if (M16 && !stager) {                                    // (WS: the multipliers only)
+    } else if (M16 && !stager) {                                    // (WS: the multipliers only) step 0 of chunk 0 into fragment set 0, landed before the dispatch over ML
         sgpr_settle(wp);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) { bXlo[n] = n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane); bXhi[n] = n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane); }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
-        wp += STEP * 16;
-        vm_wait<0>(bXlo[0], bXlo[1], bXhi[0], bXhi[1]);
-        vm_wait<0>(bY[0], bY[1], bY[2], bY[3]);
+        if constexpr (WS && M16) {
+            ws16_request(fs[0]);
+            ws16_landed(fs[0]);
+        }
     } else if (!stager) {
         sgpr_settle(wp);                                            // wp has just been made uniform by v_readfirstlane
 #pragma unroll
@@ -385,8 +393,82 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     __syncthreads();
     OAI_WSTAMP(1);
 
+    // ---- WS + M16 (round 5): the multipliers' chunks, SLICE-MAJOR on TWO whole fragment sets.  The first tap-pair version of this form (round 4) kept the
+    // two-group form's pass order on 32 fragment registers: X' / Y' were re-requested 48-64 MFMAs before their next use, and a multiplier has its SIMD to
+    // itself -- nobody covers the rest of an L2 round trip: +15 % clock, MFMA-busy 0.55 -> 0.50, nothing gained.  Here a step runs slice by slice -- per
+    // slice m: B a0(m).Y', A a0(m).X', C a1(m).X' (24 MFMAs; every accumulator still sees B, A, C in this order: bit-identical to the pass-major order) --
+    // so only ONE slice's A fragments are live (24 registers instead of 32 + 32), and the registers that frees hold a SECOND fragment set: the fragments of
+    // step j + 1 are requested at the top of step j, a whole step (96 MFMAs, ~0.7 us) ahead, and waited for with vmcnt(0) at the top of step j + 1.  Five steps
+    // per chunk is odd, so the set a chunk starts with alternates: the chunk loop is unrolled by two (P = the set of step 0).
+    auto ws16_chunk = [&](auto ml_tag, auto p_tag, int ch) __attribute__((always_inline)) {
+        constexpr int ML = decltype(ml_tag)::value, P = decltype(p_tag)::value;
+        constexpr int SL = 4 * HY * NP * 64;
+        auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
+            return *reinterpret_cast<const float4*>(Tl + off + m * SL + p * 1024);
+        };
+        auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+        };
+        compute_a16((unsigned)(P * TB));                              // (chunk ch reads T buffer ch & 1 = P: the loop below is unrolled by two)
+        float4 a0[2], a1[2];                                            // this slice's a0 / a1 fragments
+        if constexpr (ML > 0) { a0[0] = lda(a16[0], 0, 0); a0[1] = lda(a16[0], 0, 1); }
+        auto step = [&](auto jtag) __attribute__((always_inline)) {
+            constexpr int j = decltype(jtag)::value;
+            f32x4 (&cur)[8] = fs[(P + j) & 1];
+            f32x4 (&nxt)[8] = fs[(P + j + 1) & 1];
+            ws16_landed(cur);                                           // requested a whole step ago
+            __builtin_amdgcn_sched_barrier(0);
+            ws16_request(nxt);                                          // step j + 1 (behind step 4: step 0 of the next chunk)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < ML; ++m) {
+                if (j < 4) { a1[0] = lda(a16[j * 2 + 1], m, 0); a1[1] = lda(a16[j * 2 + 1], m, 1); }      // needed 16 MFMAs from here
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)                           // pass B: a0 . Y'   (step 4: [a0 | a1] . [b1 | 0])
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) mma(a0[p], cur[4 + n], acc4[m][n >> 1][p * 2 + (n & 1)]);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)                           // pass A: a0 . X'
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) mma(a0[p], cur[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+                // the next slice's a0 (the next step's slice 0 behind the last slice; nothing behind the chunk's last slice: the other T buffer)
+                const bool more = m + 1 < ML || j < 4;
+                if (more) {                                           // (a0 is dead behind pass A: straight into its registers, pass C covers the LDS latency)
+                    const int nj = m + 1 < ML ? j : j + 1, nm = m + 1 < ML ? m + 1 : 0;
+                    const unsigned off = a16[nj < 4 ? nj * 2 : 8];
+                    a0[0] = lda(off, nm, 0); a0[1] = lda(off, nm, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < 4) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)                       // pass C: a1 . X'
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) mma(a1[p], cur[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
+        // chunk end: the fragments of the next chunk's step 0 stay in flight (set P ^ 1: waited for at its top); the barrier: the stagers have finished
+        // the other T buffer, and everybody is done reading this one
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     auto run_chunks = [&](auto ml_tag) __attribute__((always_inline)) {
         constexpr int ML = decltype(ml_tag)::value;
+        if constexpr (WS && M16) {
+            int ch = 0;
+            for (; ch + 1 < nchunks; ch += 2) {
+                ws16_chunk(ml_tag, std::integral_constant<int, 0>{}, ch);
+                ws16_chunk(ml_tag, std::integral_constant<int, 1>{}, ch + 1);
+            }
+            if (ch < nchunks) ws16_chunk(ml_tag, std::integral_constant<int, 0>{}, ch);
+            return;
+        }
         for (int ch = 0; ch < nchunks; ++ch) {
             // (-DOAI_DIAG builds, OAI_DBG bits -- timing only, results wrong: 4096 no weight-fragment loads in the taps, 8192 A fragments of tap 0 for
             // every tap, 16384 transform of chunk 0 only, 32768 no DMA pieces in the taps, 65536 every weight-fragment load from ONE address
@@ -413,91 +495,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
             const unsigned char* abase = Tl + (WS ? (ch & 1) * TB : 0) + aofs;
             if constexpr (M16 && WS) {
-                // The multipliers' chunk on 16x16x32 tap pairs: the two-group form's step (below) without the halo pieces -- the stagers request
-                // those -- and without a drain at the chunk end: the fragments of the next chunk's step 0 stay in flight across the barrier.
-                constexpr int SL = 4 * HY * NP * 64;
-                auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
-                    return *reinterpret_cast<const float4*>(Tl + off + m * SL + p * 1024);
-                };
-                auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
-                };
-                compute_a16((unsigned)((ch & 1) * TB));
-                float4 af[MREP][2];
-#pragma unroll
-                for (int m = 0; m < ML; ++m)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[0], m, p);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    vm_wait<4>(bY[0], bY[1], bY[2], bY[3]);              // Y'(j) has landed; younger: lo(j), hi(j)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int m = 0; m < ML; ++m)                          // pass B: a0 . Y'
-#pragma unroll
-                        for (int p = 0; p < 2; ++p)
-#pragma unroll
-                            for (int n = 0; n < 4; ++n) mma(af[m][p], bY[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!OAI_DBG_BIT(a, 4096)) {
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
-                    }
-                    asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");      // lo(j); younger: hi(j), Y'(j + 1)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int m = 0; m < ML; ++m)                          // pass A, low couts
-#pragma unroll
-                        for (int p = 0; p < 2; ++p)
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");      // hi(j); younger: Y'(j + 1)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int m = 0; m < ML; ++m) {                        // pass A, high couts; behind each slice its a1 fragments
-#pragma unroll
-                        for (int p = 0; p < 2; ++p)
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (j < 4) {
-#pragma unroll
-                            for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j * 2 + 1], m, p);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (j < 4) {
-#pragma unroll
-                        for (int m = 0; m < ML; ++m)                      // pass C, low couts
-#pragma unroll
-                            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (!OAI_DBG_BIT(a, 4096)) { bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane); }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (j < 4) {
-#pragma unroll
-                        for (int m = 0; m < ML; ++m) {                    // pass C, high couts; behind each slice the next step's a0 fragments
-#pragma unroll
-                            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                                for (int n = 0; n < 2; ++n) mma(af[m][p], bXhi[n], acc4[m][1][p * 2 + n]);
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j < 3 ? (j + 1) * 2 : 8], m, p);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    if (!OAI_DBG_BIT(a, 4096)) { bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane); }
-                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+                // (round 5: the chunk loop of this form is ws16_chunks below -- slice-major steps on two whole fragment sets)
+                (void)abase;
             } else if constexpr (M16) {
                 // Five steps, pass order B, A, C -- a0 . Y', a0 . X', a1 . X'.  Y' is dead after the first pass: its registers take Y' of the
                 // next step a whole step ahead.  X' is live through the last two passes; so that its successor has more than pass B to land
@@ -523,8 +522,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                     for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[0], m, p);
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    constexpr int kDummy = 0; (void)kDummy;
-                    // vector-memory operations younger than Y'(j) at the top of step j: lo(j), hi(j) and the pieces requested at the end of step j - 1
+                        // vector-memory operations younger than Y'(j) at the top of step j: lo(j), hi(j) and the pieces requested at the end of step j - 1
                     const int npp = j > 0 ? np_of(j - 1) : 0;           // (step 0: the fragments were requested at the chunk's top, nothing behind them)
                     if (npp == 0) vm_wait<4>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<6>(bY[0], bY[1], bY[2], bY[3]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -658,8 +656,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                     if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
 #pragma unroll
                     for (int m = 0; m < ML; ++m) {
-                        constexpr int kDummy = 0; (void)kDummy;
-                        const int step = t * ML + m;                     // aa[step & 1] holds (t, m)
+                                const int step = t * ML + m;                     // aa[step & 1] holds (t, m)
                         __builtin_amdgcn_sched_barrier(0);
                         if (m + 1 < ML) load_pair(aa[(step + 1) & 1], t, m + 1);
                         else if (t + 1 < 9) load_pair(aa[(step + 1) & 1], t + 1, 0);
@@ -695,8 +692,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 f32x4 (&bn)[2][NREP] = bq[(t + 1) & 1];
                 // B(t) was requested in tap t-1, in front of that tap's pieces: they may stay in flight
                 {
-                    constexpr int kDummy = 0; (void)kDummy;
-                    const int younger = t > 0 ? pieces_in_tap(t - 1) : 0;
+                        const int younger = t > 0 ? pieces_in_tap(t - 1) : 0;
                     if (younger == 0) vm_wait<0>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
                     else if (younger == 1) vm_wait<1>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
                     else vm_wait<2>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
@@ -829,7 +825,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     // fragments requested past the last tap / step: never used, but still in flight INTO their registers -- the wait names them, so that they stay
     // allocated until it has executed (a bare wait lets the compiler reuse the "dead" registers between the loop exit and the wait: unet_sres.h)
     if constexpr (WS && M16) {
-        if (!stager) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bY[0]), "+v"(bY[1]), "+v"(bY[2]), "+v"(bY[3]), "+v"(bXlo[0]), "+v"(bXlo[1]), "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+        if (!stager) { ws16_landed(fs[0]); ws16_landed(fs[1]); }
     } else if constexpr (D > 1) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]), "+v"(bq[1][1][1]),
                      "+v"(bq[NB - 1][0][0]), "+v"(bq[NB - 1][0][1]), "+v"(bq[NB - 1][1][0]), "+v"(bq[NB - 1][1][1]) :: "memory");
@@ -882,7 +878,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
                 if (m == F) continue;
-                constexpr int kDummy = 0; (void)kDummy;
                 const int slot = F * 3 + (m > F ? m - 1 : m);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
