@@ -76,6 +76,10 @@ struct oai_unet {
     int opt_dead_stores = 1;            // option "dead_stores": 1 = the encoder does not write the part of a skip tensor that the decoder never reads
     int opt_census = 1;                 // option "census": 0 = the kernels do not record the per-layer maxima (A/B timing of the bookkeeping; no LOW flag)
     unsigned char* zero_rec = nullptr;  // 64 zero bytes: source of halo voxels outside the tile for the LDS-DMA staging
+    int opt_persist = 0;                // option "persistent": bit 0 = the specialised 64-cout Winograd form (dc2) with persistent workgroups, the staging waves one block
+                                        // ahead (conv3_wino_sres<..., PS>; bit-identical maps)
+    int* ps_plan = nullptr;             // the block plan of a persistent launch (wino_plan_kernel): 288 + 8 x 256 ints
+    int n_cus = 256;                    // compute units of the device (persistent launches: one workgroup per CU)
     int xcd_group = 32;                 // logical blocks per XCD deal (option "xcd_group"; 0 = launch order)
     bool sres_ring = false;             // MREP 2 with the six-slot z-plane ring (option "sres_ring")
     int b_lds = 0;                      // weight fragments through a three-slot LDS ring shared by the workgroup (option "b_lds")
@@ -742,6 +746,41 @@ static bool wino_m16_64(const oai_unet* h, const Layer& L, int cout) {
     return cout % 128 != 0 && (h->opt_wino & 32) && !(h->opt_wino & (4 | 8)) && L.panel_wino16 && wino_ws_fits();
 }
 
+// The block plan of one persistent launch of conv3_wino_sres<..., PS> (one workgroup): per tile the sub-box of the block grid that meets the tile's own
+// box, the number of blocks in front of every tile, the total -- and the XCDs' counters back at zero.  Layout: ConvArgs::ps_plan.
+constexpr int kPsMaxTiles = 256;
+__global__ void __launch_bounds__(kPsMaxTiles) wino_plan_kernel(int* __restrict__ plan, const int* __restrict__ boxes, int ntiles, int lo0, int lo1, int lo2, int hi0, int hi1, int hi2,
+                                                                 int tz, int ty, int tx, int nbz, int nby, int nbx, int ncb) {
+    __shared__ int cnt[kPsMaxTiles];
+    const int t = threadIdx.x;
+    int c = 0;
+    if (t < ntiles) {
+        const int llo[3] = {lo0, lo1, lo2}, lhi[3] = {hi0, hi1, hi2}, bs[3] = {tz, ty, tx}, nbk[3] = {nbz, nby, nbx};
+        int b0[3], nn[3];
+        bool any = true;
+        for (int i = 0; i < 3; ++i) {
+            int l = llo[i], h = lhi[i];
+            if (boxes) { l = max(l, boxes[6 * t + i]); h = min(h, boxes[6 * t + 3 + i]); }
+            any = any && l < h;
+            b0[i] = any ? (l - llo[i]) / bs[i] : 0;                                  // first block whose [o, o + bs) reaches l
+            const int b1 = any ? min(nbk[i], (h - llo[i] + bs[i] - 1) / bs[i]) : 0;     // one past the last block that starts below h
+            nn[i] = max(0, b1 - b0[i]);
+        }
+        c = any ? nn[0] * nn[1] * nn[2] * ncb : 0;
+        int* sb = plan + 288 + 8 * t;
+        sb[0] = b0[0]; sb[1] = nn[0]; sb[2] = b0[1]; sb[3] = nn[1]; sb[4] = b0[2]; sb[5] = nn[2];
+    }
+    cnt[t] = c;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < ntiles; ++i) { plan[16 + i] = run; run += cnt[i]; }
+        plan[16 + ntiles] = run;
+        plan[8] = run; plan[9] = ntiles;
+        for (int i = 0; i < 8; ++i) plan[i] = 0;
+    }
+}
+
 // One launch of conv3_wino_sres (unet_wino.h) with blocks of 4 x TY x 2 NP over `box` (box.lo[2] even)
 template <int TY, int NP>
 static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
@@ -777,6 +816,14 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
         else if (wino_m16_64(h, L, a.Cout)) {                                                          // the multipliers' taps on v_mfma_f32_16x16x32_f16
             a.wpanel = L.panel_wino16;
             conv3_wino_sres<1, TY, NP, 1, true, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
+        } else if (h->opt_persist && h->ps_plan && ntiles <= kPsMaxTiles && (a.C0 + 15) / 16 + (a.C1 + 15) / 16 >= 6) {
+            // persistent workgroups, one per CU, the staging waves one block ahead (unet_wino.h, PS): the plan first, same stream
+            wino_plan_kernel<<<1, kPsMaxTiles, 0, st>>>(h->ps_plan, a.boxes, ntiles, a.lo[0], a.lo[1], a.lo[2], a.hi[0], a.hi[1], a.hi[2], 4, TY, 2 * NP, a.nbz, a.nby, a.nbx, a.ncb);
+            OAI_CHECK_LAUNCH();
+            a.ps_plan = h->ps_plan;
+            const unsigned total = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+            const unsigned pgrid = total < (unsigned)h->n_cus ? total : (unsigned)h->n_cus;
+            conv3_wino_sres<1, TY, NP, 1, true, false, true><<<pgrid, 512, 0, st>>>(a, h->zero_rec);
         } else conv3_wino_sres<1, TY, NP, 1, true><<<grid, 512, 0, st>>>(a, h->zero_rec);              // one block of 64 couts: four waves multiply, four stage
     } else if (wino_m16_64(h, L, a.Cout)) {                                          // (the y strip's two T buffers would not fit: the eight waves split the z slices --
         a.wpanel = L.panel_wino16;                                                     //  on the same tap pairs as the layer's other shapes: one summation order per layer)
@@ -1208,6 +1255,16 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
         h->allocs.push_back(z);
         h->zero_rec = reinterpret_cast<unsigned char*>(z);
         (void)hipMemset(z, 0, 256);
+        void* pp = nullptr;
+        if (hipMalloc(&pp, (288 + 8 * kPsMaxTiles) * sizeof(int)) != hipSuccess) { delete h; return set_error(OAI_ERR_HIP, "oai_unet_create: hipMalloc failed"); }
+        h->allocs.push_back(pp);
+        h->ps_plan = reinterpret_cast<int*>(pp);
+        (void)hipMemset(pp, 0, (288 + 8 * kPsMaxTiles) * sizeof(int));
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
+        }
         void* c = nullptr;
         if (hipMalloc(&c, 18 * 16 * sizeof(unsigned) + 256) != hipSuccess) { delete h; return set_error(OAI_ERR_HIP, "oai_unet_create: hipMalloc failed"); }
         h->allocs.push_back(c);
@@ -1326,6 +1383,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
     } else if (!strcmp(name, "m16")) {                 // the direct kernel's taps on v_mfma_f32_16x16x32_f16 tap pairs (another summation order; default 1)
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: m16 must be 0 or 1");
         h->opt_m16 = value;
+    } else if (!strcmp(name, "persistent")) {          // persistent workgroups with the staging one block ahead (bit 0: the specialised 64-cout Winograd form); bit-identical maps
+        OAI_CHECK_ARG(value >= 0 && value <= 1, "oai_unet_set_option: persistent is a mask (bit 0)");
+        h->opt_persist = value;
     } else if (!strcmp(name, "m16_layers")) {
         OAI_CHECK_ARG(value >= 0 && value <= 0x3FFFF, "oai_unet_set_option: m16_layers is a mask over the 18 layers");
         h->opt_m16_layers = value;

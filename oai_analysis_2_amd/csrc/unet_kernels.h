@@ -97,6 +97,7 @@ struct ConvArgs {
     int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
     unsigned long long* stamps = nullptr;    // -DOAI_DIAG builds: device array of phase cycle sums (oai_diag_stamps); never set in production
     int nblocks = 0, xcd_group = 0;          // split-resident kernel: true workgroup count and the XCD dealing granularity (see xcd_block_id)
+    int* ps_plan = nullptr;                  // conv3_wino_sres<..., PS>: the launch's block plan (wino_plan_kernel): counters, block count, per-tile prefix and sub-boxes
     // split-resident kernel only: dc0 (1x1x1 conv) + sigmoid / threshold + centre crop fused into dc1's epilogue.  When head_w is
     // set the layer's own output is NOT written; every block voxel inside head_boxes[tile] goes to the kept-centre blocks instead.
     const float* head_w = nullptr;           // [ncls][Cout]

@@ -70,8 +70,13 @@ namespace oai {
 // tile at row 16 p + 4 (lane >> 4) + i, cout column 16 q + (lane & 15).  Weight fragments: pack_wino16_panel, 40 KiB per chunk and 64 couts
 // (36 in the 32x32 form), X' double-buffered, Y' reloaded behind pass B: 48 registers.  Every accumulator sees a0.b0 (two taps at once),
 // a0.b1, a1.b0 per step: another summation order than the 32x32 form's, same arithmetic class (tests: the Winograd gates).
-template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false>
+// PS (round 5; WS only): PERSISTENT workgroups.  One workgroup per CU pulls blocks from a per-XCD counter (ConvArgs::ps_plan, wino_plan_kernel) until none is
+// left, and the staging waves run ONE BLOCK AHEAD: during the last two chunks of a block they request and transform chunk 0 of the next block, so the
+// multipliers go from a block's epilogue straight into the next block's taps -- no prologue (request, L2 / HBM round trip, transform: ~5 us of a ~70-us
+// block) and no workgroup launch in between (~4 us of an idle CU per block: profiles/r04_wino_stream.md section 6).  Same arithmetic, same order: bit-identical.
+template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false, bool PS = false>
 __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+    static_assert(!PS || (WS && !M16), "persistent workgroups: the specialised form");
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
     static_assert(!M16 || MS == 1 || (NG == 1 && !WS), "the 16x16x32 taps: the four-slice forms (two groups, or specialised waves) and the slice-split 64-cout form");
@@ -100,32 +105,54 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     // latest end of any wave (the span of the launch: span x CUs - the workgroups' own time = what a CU spends between workgroups + the tail)
     // [3] exchange (send, receive, three barriers), [4] output transform + image writes + barrier, [5] copy-out (+ fused pool) -- parts of [2], both halves
     unsigned long long wst[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, wep[3] = {0, 0, 0}, wlast = 0;
+    // PS: [0] block switch (end barrier -> first chunk), [1] chunk loop, [2] epilogue up to its end barrier, [3] of [1]: at the chunk-end barriers (multiplying wave 0);
+    // [4] the staging wave 4 at the chunk-end barriers (its slack), [5] its epilogue; [8] blocks
+    unsigned long long pst[6] = {0, 0, 0, 0, 0, 0}, pslast = wst[0], psblocks = 0;
+#define OAI_PSTAMP(i) do { if (PS && a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); pst[i] += now_ - pslast; pslast = now_; } } while (0)
 #define OAI_WSTAMP(i) do { if (a.stamps) wst[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define OAI_WEP0() do { if (a.stamps) wlast = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define OAI_WEP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); wep[i] += now_ - wlast; wlast = now_; } } while (0)
 #else
+#define OAI_PSTAMP(i) do { } while (0)
 #define OAI_WSTAMP(i) do { } while (0)
 #define OAI_WEP0() do { } while (0)
 #define OAI_WEP(i) do { } while (0)
 #endif
     const int grp = (MS == 2 || WS) ? 0 : wave >> 2, zp = MS == 2 ? wave >> 2 : 0, f = wave & 3, gtid = tid & 255;
     const bool stager = WS && __builtin_amdgcn_readfirstlane(wave) >= 4;      // WS: waves 4-7 stage, waves 0-3 multiply (a scalar condition: the branches on it are uniform)
-    int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
-    if (id < 0) return;
-    const int cbg = id % a.ncb; id /= a.ncb;                      // a.ncb = Cout / (64 NG) for this kernel
-    const int bx = id % a.nbx; id /= a.nbx;
-    const int by = id % a.nby; id /= a.nby;
-    const int bz = id % a.nbz; id /= a.nbz;
-    const int tile = id;
-    const int cb = cbg * NG + grp;                                // this group's block of 64 couts
-    const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * TY, ox0 = a.lo[2] + bx * TX;      // a.lo[2] is even (host)
+    // ---- the block (PS: re-assigned per block by set_block; otherwise fixed)
+    const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+    int tile, cb, oz0, oy0, ox0, m_lo, m_hi;
     int blo[3], bhi[3];
-    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
-    if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + TY <= blo[1] || ox0 >= bhi[2] || ox0 + TX <= blo[2]) return;
+    const unsigned char *s0, *s1;
+    // (PS: the six ints of a.boxes[tile] can be handed in -- loaded a phase earlier, so that the switch to the next block does not wait for them)
+    auto set_block = [&](int tile_, int bz, int by, int bx, int cbg, const int* pre = nullptr) __attribute__((always_inline)) -> bool {
+        tile = tile_;
+        cb = cbg * NG + grp;                                      // this group's block of 64 couts
+        oz0 = a.lo[0] + bz * TZ; oy0 = a.lo[1] + by * TY; ox0 = a.lo[2] + bx * TX;      // a.lo[2] is even (host)
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { blo[i] = max(a.lo[i], pre[i]); bhi[i] = min(a.hi[i], pre[3 + i]); }
+            if (!(blo[0] < bhi[0] && blo[1] < bhi[1] && blo[2] < bhi[2])) return false;
+        } else if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return false;
+        if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + TY <= blo[1] || ox0 >= bhi[2] || ox0 + TX <= blo[2]) return false;
+        m_lo = max(0, blo[0] - oz0); m_hi = min(TZ, bhi[0] - oz0);
+        s0 = reinterpret_cast<const unsigned char*>(a.src0) + srec(tile, nch0, plane, 0, 0);
+        s1 = reinterpret_cast<const unsigned char*>(a.src1) + srec(tile, nch1, plane, 0, 0);
+        return true;
+    };
+    if constexpr (!PS) {
+        int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
+        if (id < 0) return;
+        const int cbg = id % a.ncb; id /= a.ncb;                  // a.ncb = Cout / (64 NG) for this kernel
+        const int bx = id % a.nbx; id /= a.nbx;
+        const int by = id % a.nby; id /= a.nby;
+        const int bz = id % a.nbz; id /= a.nbz;
+        if (!set_block(id, bz, by, bx, cbg)) return;
+    }
 
     const int row = lane & 31, half = lane >> 5;
-    const int yl = row / NP, pr = row % NP;                       // this lane's A row: y, x pair
-    const int m_lo = max(0, blo[0] - oz0), m_hi = min(TZ, bhi[0] - oz0);
 
     f32x16 acc[M16 ? 1 : MREP][M16 ? 1 : NREP];
     f32x4 acc4[M16 ? MREP : 1][M16 ? NREP : 1][4];                    // M16: [m][n][p * 2 + q], element i at row 16 p + 4 (lane >> 4) + i, column 16 q + (lane & 15)
@@ -146,11 +173,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         if constexpr (M16) return acc4[m][n][r >> 2][r & 3];
         else return acc[m][n][r];
     };
-
-    const int nch0 = (a.C0 + 15) / 16, nch1 = (a.C1 + 15) / 16, nchunks = nch0 + nch1;
-    const size_t plane = (size_t)a.D * a.H * a.W;
-    const unsigned char* s0 = reinterpret_cast<const unsigned char*>(a.src0) + srec(tile, nch0, plane, 0, 0);
-    const unsigned char* s1 = reinterpret_cast<const unsigned char*>(a.src1) + srec(tile, nch1, plane, 0, 0);
 
     // ---- staging plan: piece L = it * NT + tid of the raw box -> byte offset of its 16 bytes inside a chunk plane, or kNoPiece (outside
     // the tile = Conv3d's zero padding, pad piece, beyond the box) -> the zero record
@@ -261,29 +283,57 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     const int sw = wave & 3;
     unsigned char* const raw_w = raw + sw * (WNIT * 1024);
     unsigned woff[WS ? WNIT : 1];
-    if constexpr (WS) {
+    // this staging wave's piece offsets for the block at (z0, y0, x0)
+    auto stage_plan = [&](unsigned (&wo)[WS ? WNIT : 1], int z0, int y0, int x0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < (WS ? WNIT : 0); ++it) {
+            const int q = it * 64 + lane;
+            const int rj = q / RS, c = q - rj * RS;
+            const int r = sw + 4 * rj, hz = r / HY, hy = r - hz * HY;
+            const int term = c / (2 * HX), hx = (c - term * 2 * HX) >> 1, hf = c & 1;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = rj < RPW && c < 4 * HX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            wo[WS ? it : 0] = ok ? ((unsigned)((gz * a.H + gy) * a.W + gx) << 6) | (unsigned)(term * 32 + hf * 16) : kNoPiece;
+        }
+    };
+    if constexpr (WS && !PS) stage_plan(woff, oz0, oy0, ox0);
+    // PS: the block-independent part of the plan, once per kernel: (hz, hy, hx, term / half, piece exists) per DMA instruction, packed; per block only the
+    // origin is added (the divisions of stage_plan cost a staging wave ~3 us per block)
+    unsigned wpk[PS ? WNIT : 1];
+    if constexpr (PS) {
 #pragma unroll
         for (int it = 0; it < WNIT; ++it) {
             const int q = it * 64 + lane;
             const int rj = q / RS, c = q - rj * RS;
             const int r = sw + 4 * rj, hz = r / HY, hy = r - hz * HY;
             const int term = c / (2 * HX), hx = (c - term * 2 * HX) >> 1, hf = c & 1;
-            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
-            const bool ok = rj < RPW && c < 4 * HX && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            woff[it] = ok ? ((unsigned)((gz * a.H + gy) * a.W + gx) << 6) | (unsigned)(term * 32 + hf * 16) : kNoPiece;
+            wpk[it] = (unsigned)hz | (unsigned)hy << 3 | (unsigned)hx << 8 | (unsigned)(term * 2 + hf) << 13 | (rj < RPW && c < 4 * HX ? 1u << 15 : 0u);
         }
     }
-    auto stage_request = [&](int ch) __attribute__((always_inline)) {
+    auto stage_plan_fast = [&](unsigned (&wo)[WS ? WNIT : 1], int z0, int y0, int x0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < (PS ? WNIT : 0); ++it) {
+            const unsigned k = wpk[PS ? it : 0];
+            const int gz = z0 - 1 + (int)(k & 7), gy = y0 - 1 + (int)((k >> 3) & 31), gx = x0 - 1 + (int)((k >> 8) & 31);
+            const bool ok = (k >> 15) && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            wo[PS ? it : 0] = ok ? ((unsigned)((gz * a.H + gy) * a.W + gx) << 6) | (((k >> 13) & 3) << 4) : kNoPiece;
+        }
+    };
+    // PS: the lanes of a wave's last DMA instruction that lie beyond its pieces do not write -- the tail of the raw box holds the control words
+    constexpr int kLastLanes = WS ? RPW * RS - (WNIT - 1) * 64 : 64;
+    static_assert(!PS || kLastLanes <= 56, "PS: room for the control words behind the last piece");
+    auto stage_request_of = [&](const unsigned (&wo)[WS ? WNIT : 1], const unsigned char* b0, const unsigned char* b1, int ch) __attribute__((always_inline)) {
         const bool first = ch < nch0;
-        const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
+        const unsigned char* cbase = (first ? b0 : b1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
         const unsigned dst = lds_addr_of(raw_w);
 #pragma unroll
         for (int it = 0; it < (WS ? WNIT : 0); ++it) {
-            const unsigned char* g = (woff[WS ? it : 0] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + woff[WS ? it : 0] : zero_rec;
-            lds_dma16(g, __builtin_amdgcn_readfirstlane(dst + it * 1024));
+            const unsigned char* g = (wo[WS ? it : 0] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + wo[WS ? it : 0] : zero_rec;
+            if (!PS || it + 1 < WNIT || lane < kLastLanes) lds_dma16(g, __builtin_amdgcn_readfirstlane(dst + it * 1024));
         }
     };
-    auto stage_transform = [&](int ch) __attribute__((always_inline)) {
+    auto stage_request = [&](int ch) __attribute__((always_inline)) { stage_request_of(woff, s0, s1, ch); };
+    auto stage_transform_to = [&](unsigned char* Tdst) __attribute__((always_inline)) {
 #pragma unroll
         for (int ui = 0; ui < (RPW * 2 * NP + 63) / 64; ++ui) {
             const int idx = ui * 64 + lane;
@@ -291,18 +341,28 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 const int rj = idx / (2 * NP), rem = idx - rj * 2 * NP;
                 const int p = rem % NP, hf = rem / NP;
                 const int r = sw + 4 * rj, hz = r / HY, hy = r - hz * HY;
-                transform_unit(raw_w + (rj * RS + 4 * p + hf) * 16, hz, hy, p, hf, Tl + (ch & 1) * TB);
+                transform_unit(raw_w + (rj * RS + 4 * p + hf) * 16, hz, hy, p, hf, Tdst);
             }
         }
     };
+    auto stage_transform = [&](int ch) __attribute__((always_inline)) { stage_transform_to(Tl + (ch & 1) * TB); };
 
     // ---- A fragments: this lane's record for tap (dz, dy) = (0, 0), slice 0, and its swizzled slot per dy and term
-    const int aofs = (((zp * MREP * 4 + f) * HY + yl) * NP + pr) * 64;
-    int sl[3][2];
+    int aofs, sl[3][2];
+    unsigned wlane;                                                 // this lane's 16 bytes of a weight fragment
+    // (PS: recomputed per block from an opaque copy of the lane id -- kept live across the epilogue, the register peak of the block loop, they would be spilled)
+    auto set_lane_consts = [&]() __attribute__((always_inline)) {
+        int lq = lane;
+        if constexpr (PS) asm volatile("" : "+v"(lq));
+        const int rw = lq & 31, hf = lq >> 5;
+        aofs = (((zp * MREP * 4 + f) * HY + rw / NP) * NP + rw % NP) * 64;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) sl[dy][t] = ((t * 2 + half) ^ (((row + dy * NP) >> 2) & 3)) * 16;
+            for (int t = 0; t < 2; ++t) sl[dy][t] = ((t * 2 + hf) ^ (((rw + dy * NP) >> 2) & 3)) * 16;
+        wlane = (unsigned)lq * 16;
+    };
+    set_lane_consts();
 
     // M16: byte offset (inside T) of this lane's record slot per step and term -- lane group g = lane >> 4 reads channel half g & 1 of tap
     // 2 j + (g >> 1) (steps 0..3; term k), or of term g >> 1 of tap 8 (step 4); row r16 = lane & 15 of the 16-row tile p = 0 (p = 1: + 1024)
@@ -335,7 +395,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     const size_t wp_v = (size_t)(a.wpanel + (size_t)(cb * 4 + f) * nchunks * NSTEPS * STEP);
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(
         ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wp_v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp_v));
-    const unsigned wlane = lane * 16;
+    const unsigned char* const wp_base = wp;                        // (PS: every block starts at the panel's first tap again)
+    int pb = 0;                                                     // WS: the T buffer of the block's chunk 0 (chunk ch reads buffer (pb + ch) & 1; not PS: always 0)
 
     f32x4 fs[WS && M16 ? 2 : 1][8];                                  // [set][X' n2 0..3 | Y' n2 0..3]
     auto ws16_request = [&](f32x4 (&d)[8]) __attribute__((always_inline)) {
@@ -359,7 +420,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     constexpr int D = WS ? 2 : 1, NB = D + 1;
     f32x4 bq[NB][2][NREP];                                          // [tap % NB][term][n]
     f32x4 bXlo[2], bXhi[2], bY[4];                                  // M16: X' (the high terms b0), couts n 0, 1 and n 2, 3, and Y' (the low terms b1) of the running step
-    if (M16 && !WS) {
+    if constexpr (PS) {
+        // (the persistent driver at the end of the kernel has its own prologue, behind the first block's assignment)
+    } else if (M16 && !WS) {
         // (round 5) the fragments of a chunk's step 0 are requested at the chunk's top, in front of the transform: see run_chunks
         sgpr_settle(wp);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first raw box has landed
@@ -390,7 +453,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // its reads of the raw rows are done: they may be overwritten
         if (nchunks > 1) stage_request(1);
     }
-    __syncthreads();
+    if constexpr (!PS) __syncthreads();
     OAI_WSTAMP(1);
 
     // ---- WS + M16 (round 5): the multipliers' chunks, SLICE-MAJOR on TWO whole fragment sets.  The first tap-pair version of this form (round 4) kept the
@@ -493,7 +556,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 __builtin_amdgcn_s_barrier();                        // T is complete; the raw box is free for the next chunk's pieces
                 asm volatile("" ::: "memory");
             }
-            const unsigned char* abase = Tl + (WS ? (ch & 1) * TB : 0) + aofs;
+            const unsigned char* abase = Tl + (WS ? ((ch + pb) & 1) * TB : 0) + aofs;
             if constexpr (M16 && WS) {
                 // (round 5: the chunk loop of this form is ws16_chunks below -- slice-major steps on two whole fragment sets)
                 (void)abase;
@@ -662,6 +725,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                         else if (t + 1 < 9) load_pair(aa[(step + 1) & 1], t + 1, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         float4 (&ac)[2] = aa[step & 1];
+                        if (OAI_DBG_BIT(a, 262144)) { asm volatile("" :: "v"(ac[0].x), "v"(ac[0].w), "v"(ac[1].x), "v"(ac[1].w)); continue; }      // (timing only: the taps without their MFMAs)
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(ac[0], __builtin_bit_cast(float4, bc[0][n]), acc[m][n]);      // a0.b0
 #pragma unroll
@@ -674,8 +738,10 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 // chunk end: the fragments of the next chunk's taps 0 and 1 stay in flight (waited for there); the barrier: the stagers have
                 // finished the other T buffer, and everybody is done reading this one
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                OAI_PSTAMP(1);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                OAI_PSTAMP(3);
                 continue;
             }
             auto load_a = [&](float4 (&dst)[MREP], int t, int k) __attribute__((always_inline)) {
@@ -740,12 +806,16 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
         }
     };
-    const int mlb = m_lo == 0 ? m_hi : TZ;                          // live z slices of the block (workgroup-uniform) ...
-    const int ml = min(MREP, max(0, mlb - zp * MREP));              // ... and of this wave (wave-uniform; MS = 2: the upper pair of a 1- or 2-slice block idles through the taps)
+    int mlb, ml;
+    auto set_ml = [&]() __attribute__((always_inline)) {
+        mlb = m_lo == 0 ? m_hi : TZ;                                // live z slices of the block (workgroup-uniform) ...
+        ml = min(MREP, max(0, mlb - zp * MREP));                    // ... and of this wave (wave-uniform; MS = 2: the upper pair of a 1- or 2-slice block idles through the taps)
+    };
+    if constexpr (!PS) set_ml();
     // copy-out of cout half n of the block's output image (LDS, 128 B per voxel) to the output tensor: pieces [it0, it1) of this thread
     constexpr int TV = TZ * TY * TX;                                // 256 voxels
     constexpr int EIT = TV * 8 / 256;                               // 16-byte pieces per thread and cout half
-    unsigned char* const xb = lds + grp * XB;                       // exchange buffer, then output image, of this group
+    unsigned char* xb = lds + grp * XB;                             // exchange buffer, then output image, of this group (PS: the T buffer that the block's last chunk has read)
     unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
     const int nco = (a.Cout + 15) / 16;
     auto copy_out = [&](int n, int it0, int it1, const int (&clo)[3], const int (&chi)[3]) __attribute__((always_inline)) {
@@ -786,53 +856,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             for (int i = 0; i < 3; ++i) { clo[i] = max(clo[i], sb[i] - a.store_grow); chi[i] = min(chi[i], sb[3 + i] + a.store_grow); }
         }
     };
-    if (stager) {
-        // WS, waves 4-7: while the multipliers run the taps of chunk ch, transform the rows of chunk ch + 1 (requested a chunk ago: the wait is
-        // short) into the other T buffer, then request chunk ch + 2 into the same rows; one barrier per chunk, the multipliers' chunk-end one
-        for (int ch = 0; ch < nchunks; ++ch) {
-            if (ch + 1 < nchunks) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                stage_transform(ch + 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (ch + 2 < nchunks) stage_request(ch + 2);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        // the multipliers' epilogue: its four barriers per cout half, then this wave's half of the image's copy-out (the next half's first barrier
-        // waits for these LDS reads before the exchange overwrites the image)
-        int sclo[3], schi[3];
-        store_box(sclo, schi);
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) {
-            for (int i = 0; i < 4; ++i) __syncthreads();
-            copy_out(n, EIT / 2, EIT, sclo, schi);
-        }
-        return;
-    }
-    if constexpr (MS == 1) {
-        if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
-        else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
-        else if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
-        else run_chunks(std::integral_constant<int, 1>{});
-    } else {
-        if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
-        else if (ml == 1) run_chunks(std::integral_constant<int, 1>{});
-        else run_chunks(std::integral_constant<int, 0>{});
-    }
-
-    // fragments requested past the last tap / step: never used, but still in flight INTO their registers -- the wait names them, so that they stay
-    // allocated until it has executed (a bare wait lets the compiler reuse the "dead" registers between the loop exit and the wait: unet_sres.h)
-    if constexpr (WS && M16) {
-        if (!stager) { ws16_landed(fs[0]); ws16_landed(fs[1]); }
-    } else if constexpr (D > 1) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]), "+v"(bq[1][1][1]),
-                     "+v"(bq[NB - 1][0][0]), "+v"(bq[NB - 1][0][1]), "+v"(bq[NB - 1][1][0]), "+v"(bq[NB - 1][1][1]) :: "memory");
-    }
-    OAI_WSTAMP(2);
-    // ---- epilogue
-    const unsigned seen = census_peek(a.census);                    // (waited for under the epilogue)
+    // ---- epilogue (its constants are loaded behind the chunk loop: load_epilogue_consts)
+    unsigned seen = 0;
     float vmax = 0.0f;
     bool nonfinite = false;                                         // an output inside the box that is inf / NaN (an overflowed t): fmaxf would drop the NaN silently
     unsigned umax = 0;                                              // (MS = 1: the same as the largest |v| BIT PATTERN inside the box -- NaN > inf > every finite value as unsigned)
@@ -840,16 +865,18 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     // this lane's cout column: lane & 31 of the 32-cout half n -- M16: columns 16 q + (lane & 15), q = 0, 1 (element (p, q, i) = r of the tile)
     const int col16 = lane & 15, rq16 = lane >> 4;
     float scv[NREP][M16 ? 2 : 1], shv[NREP][M16 ? 2 : 1];
-#pragma unroll
-    for (int n = 0; n < NREP; ++n)
-#pragma unroll
-        for (int q = 0; q < (M16 ? 2 : 1); ++q) {
-            const int co = cb * 64 + n * 32 + (M16 ? q * 16 + col16 : row);
-            scv[n][q] = co < a.Cout ? a.scale[co] : 0.0f; shv[n][q] = co < a.Cout ? a.shift[co] : 0.0f;
-            asm volatile("" : "+v"(scv[n][q]), "+v"(shv[n][q]));
-        }
     int clo[3], chi[3];
-    store_box(clo, chi);
+    auto load_epilogue_consts = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int q = 0; q < (M16 ? 2 : 1); ++q) {
+                const int co = cb * 64 + n * 32 + (M16 ? q * 16 + col16 : row);
+                scv[n][q] = co < a.Cout ? a.scale[co] : 0.0f; shv[n][q] = co < a.Cout ? a.shift[co] : 0.0f;
+                asm volatile("" : "+v"(scv[n][q]), "+v"(shv[n][q]));
+            }
+        store_box(clo, chi);
+    };
     // wave F (= frequency F during the taps) finishes z slice F
     auto finish = [&](auto ftag) __attribute__((always_inline)) {
         constexpr int F = decltype(ftag)::value;
@@ -938,7 +965,33 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
             __syncthreads();
             OAI_WEP(1);
-            copy_out(n, 0, WS ? EIT / 2 : EIT, clo, chi);            // (WS: the staging waves, idle since the last chunk, take the other half of the pieces)
+            if constexpr (PS) {
+                // the last half's image is written: the accumulators are dead.  The weight fragments of the NEXT block's taps 0 .. D - 1, from the panel's first
+                // tap again; they land under the copy-out and are waited for behind it -- before any control flow (unet_sres.h: asm loads and branches)
+                if (n == NREP - 1) {
+                    const unsigned char* wq = wp_base;                // (a local: `wp` assigned inside the branches on the wave's frequency would stop being uniform for the compiler)
+                    sgpr_settle(wq);
+                    set_lane_consts();
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int nn = 0; nn < NREP; ++nn) bq[d][k][nn] = k == 0 ? (nn == 0 ? gload16_asm<0>(wq, wlane) : gload16_asm<1024>(wq, wlane))
+                                                                                  : (nn == 0 ? gload16_asm<2048>(wq, wlane) : gload16_asm<3072>(wq, wlane));
+                        wq += STEP * 16;
+                    }
+                }
+            }
+            // (WS: the staging waves, idle since the last chunk, take the other half of the pieces.  PS, measured: ALL pieces of the last half on the staging waves, so
+            //  that the multipliers' wait for the next block's fragments below is not a wait for copy-out stores as well: +1 ms per pass -- the end barrier then waits
+            //  for the staging waves' sixteen pieces)
+            copy_out(n, 0, WS ? EIT / 2 : EIT, clo, chi);
+            if constexpr (PS) {
+                if (n == NREP - 1)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]),
+                                 "+v"(bq[D - 1][0][0]), "+v"(bq[D - 1][0][1]), "+v"(bq[D - 1][1][0]), "+v"(bq[D - 1][1][1]) :: "memory");
+            }
             if constexpr (TY == 8 && NP == 4) if (a.pool_out && !(OAI_EXP & 2)) {       // (main shape only: the host asks for it where the box is whole blocks of it)
                 // MaxPool3d(2) fused (ec3 / ec5; networks.py:117,122), from the block's image: thread = (pooled voxel, 4 channels of one of the two
                 // 16-channel records); the pooled record keeps the (h0, h1) PAIR of the window's largest joined value -- the rule of
@@ -1071,23 +1124,281 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
             }
         }
     };
-    if constexpr (MS == 1) {
-        if (f == 0) finish(std::integral_constant<int, 0>{});
-        else if (f == 1) finish(std::integral_constant<int, 1>{});
-        else if (f == 2) finish(std::integral_constant<int, 2>{});
-        else finish(std::integral_constant<int, 3>{});
+    auto finish_block = [&]() __attribute__((always_inline)) {
+        if constexpr (MS == 1) {
+            if (f == 0) finish(std::integral_constant<int, 0>{});
+            else if (f == 1) finish(std::integral_constant<int, 1>{});
+            else if (f == 2) finish(std::integral_constant<int, 2>{});
+            else finish(std::integral_constant<int, 3>{});
+        } else {
+            if (f == 0) finish2(std::integral_constant<int, 0>{});
+            else if (f == 1) finish2(std::integral_constant<int, 1>{});
+            else if (f == 2) finish2(std::integral_constant<int, 2>{});
+            else finish2(std::integral_constant<int, 3>{});
+        }
+    };
+    if constexpr (PS) {
+        // ---- PS: the persistent driver.  Control words (LDS, behind the last staging wave's pieces): two slots of {tile, bz, by, bx, cbg, valid}
+        int* const ctl = reinterpret_cast<int*>(raw + RAWB - 64);
+        int* const planw = a.ps_plan;                               // [0..7] the XCDs' counters, [8] blocks, [9] tiles, [16 + t] blocks in front of tile t, [288 + 8 t] tile t's {bz0, nbz, by0, nby, bx0, nbx}
+        const int ps_home = (int)blockIdx.x & 7;                    // (workgroups are dealt round-robin to the XCDs: neighbours in the list meet in one L2)
+        // The next block of this workgroup -> ctl[slot]: an eighth of the list per XCD, pulled in order; an XCD that runs dry takes from the next one.  The
+        // fetch is a chain of three dependent memory round trips (counter, prefix table, the tile's sub-box); the fetching wave walks it ONE STEP PER CHUNK,
+        // behind its staging work: every step's loads are waited for by the vmcnt(0) that opens the next chunk's staging anyway.
+        int f_state = 0, f_tries = 0, f_k = 0, f_g = -1, f_p[4] = {0, 0, 0, 0}, f_tl = 0, f_p0 = 0, f_sb[6] = {0, 0, 0, 0, 0, 0};
+        auto fetch_issue_atomic = [&]() __attribute__((always_inline)) {
+            const int x = (ps_home + f_tries) & 7;
+            f_k = lane == 0 ? atomicAdd(planw + x, 1) : 0;
+        };
+        // one step; returns true when ctl[slot] has been written
+        auto fetch_step = [&](int slot) __attribute__((always_inline)) -> bool {
+            const int n = planw[8], nt = planw[9];
+            if (f_state == 0) { fetch_issue_atomic(); f_state = 1; return false; }
+            if (f_state == 1) {
+                const int x = (ps_home + f_tries) & 7;
+                const int st = (int)(((long long)n * x) >> 3), en = (int)(((long long)n * (x + 1)) >> 3);
+                const int k = __builtin_amdgcn_readfirstlane(f_k);
+                if (k < en - st) {
+                    f_g = st + k;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int t = q * 64 + lane; f_p[q] = t < nt ? planw[16 + t] : 0x7FFFFFFF; }
+                    f_state = 2;
+                    return false;
+                }
+                if (++f_tries < 8) { fetch_issue_atomic(); return false; }
+                f_g = -1; f_state = 3;                               // every range is dry: no block
+            }
+            if (f_state == 2) {
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cnt += __popcll(__builtin_amdgcn_ballot_w64(f_p[q] <= f_g));
+                f_tl = cnt - 1;
+                f_p0 = planw[16 + f_tl];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) f_sb[i] = planw[288 + f_tl * 8 + i];
+                f_state = 3;
+                return false;
+            }
+            int o[6] = {0, 0, 0, 0, 0, 0};
+            if (f_g >= 0) {
+                int r = f_g - f_p0;
+                o[4] = r % a.ncb; r /= a.ncb;
+                o[3] = f_sb[4] + r % f_sb[5]; r /= f_sb[5];
+                o[2] = f_sb[2] + r % f_sb[3];
+                o[1] = f_sb[0] + r / f_sb[3];
+                o[0] = f_tl; o[5] = 1;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ctl[slot * 8 + i] = o[i];
+            }
+            f_state = 0;
+            return true;
+        };
+        int nb[6];
+        auto read_ctl = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nb[i] = __builtin_amdgcn_readfirstlane(ctl[slot * 8 + i]);
+        };
+        const bool fetcher = __builtin_amdgcn_readfirstlane(wave) == 4;
+        if (fetcher) { while (!fetch_step(0)) { } }
+        __syncthreads();
+        read_ctl(0);
+        if (!nb[5]) return;                                         // (more workgroups than blocks)
+        set_block(nb[0], nb[1], nb[2], nb[3], nb[4]);
+        seen = census_peek(a.census);
+        // the first block's prologue: as in the plain form
+        if (stager) {
+            stage_plan_fast(woff, oz0, oy0, ox0);
+            stage_request(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage_transform_to(Tl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (nchunks > 1) stage_request(1);
+        } else {
+            sgpr_settle(wp);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) bq[d][k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
+                                                                        : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
+                wp += STEP * 16;
+            }
+            vm_wait<0>(bq[D - 1][0][0], bq[D - 1][0][1], bq[D - 1][1][0], bq[D - 1][1][1]);
+        }
+        __syncthreads();
+        int slot = 0;
+        int nbox[6];                                                // a.boxes[next tile], loaded a phase before the switch
+        auto load_nbox = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nbox[i] = a.boxes ? a.boxes[6 * nb[0] + i] : (i < 3 ? a.lo[i] : a.hi[i - 3]);
+        };
+        // (two loops, one per role: in ONE loop with a branch on the role everything a role keeps across blocks is live through the other role's code too)
+        if (stager) {
+            for (;;) {
+                const int pe = (pb + nchunks) & 1;                   // the T buffer of the NEXT block's chunk 0; the other one is free behind the last chunk: the epilogue's buffer
+                bool have_next = false, fetched = false;
+                // One block ahead: chunk ch + 1 of this block is transformed while the multipliers run chunk ch; behind the block's last chunk come chunk 0 of the
+                // NEXT block (requested during chunk nchunks - 2, transformed during chunk nchunks - 1) and the request of its chunk 1.  (host: nchunks >= 6)
+                unsigned woffN[WS ? WNIT : 1];
+                const unsigned char *s0N = nullptr, *s1N = nullptr;
+                for (int ch = 0; ch < nchunks; ++ch) {
+                    unsigned char* const tgt = Tl + ((pb + ch + 1) & 1) * TB;
+                    if (ch == nchunks - 2) {                         // the next block is known (written by chunk nchunks - 3 at the latest, one barrier ago)
+                        read_ctl(slot ^ 1);
+                        have_next = nb[5] != 0;
+                    }
+                    if (ch + 1 < nchunks) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        stage_transform_to(tgt);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (ch + 2 < nchunks) stage_request(ch + 2);
+                        else if (have_next) {
+                            stage_plan_fast(woffN, a.lo[0] + nb[1] * TZ, a.lo[1] + nb[2] * TY, a.lo[2] + nb[3] * TX);
+                            s0N = reinterpret_cast<const unsigned char*>(a.src0) + srec(nb[0], nch0, plane, 0, 0);
+                            s1N = reinterpret_cast<const unsigned char*>(a.src1) + srec(nb[0], nch1, plane, 0, 0);
+                            stage_request_of(woffN, s0N, s1N, 0);
+                            load_nbox();
+                        }
+                    } else if (have_next) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        stage_transform_to(tgt);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        stage_request_of(woffN, s0N, s1N, 1);
+                    }
+                    if (fetcher && !fetched) {                       // (behind this wave's staging of the chunk: the multipliers are still in their taps)
+                        fetched = fetch_step(slot ^ 1);
+                        if (ch >= nchunks - 3) { while (!fetched) fetched = fetch_step(slot ^ 1); }      // (the deadline: only when an XCD's range ran dry on the way)
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    OAI_PSTAMP(0);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    OAI_PSTAMP(4);
+                }
+                // the multipliers' epilogue: its four barriers per cout half, then this wave's half of the image's copy-out
+                xb = Tl + (pe ^ 1) * TB;
+                int sclo[3], schi[3];
+                store_box(sclo, schi);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+                    for (int i = 0; i < 4; ++i) __syncthreads();
+                    copy_out(n, EIT / 2, EIT, sclo, schi);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image has been read: the next transform may overwrite it
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                OAI_PSTAMP(5);
+#ifdef OAI_DIAG
+                if (!have_next && a.stamps && fetcher && lane == 0) { atomicAdd(a.stamps + 4, pst[4]); atomicAdd(a.stamps + 5, pst[5]); atomicAdd(a.stamps + 6, pst[0]); }
+#endif
+                if (!have_next) return;
+                set_block(nb[0], nb[1], nb[2], nb[3], nb[4], nbox);
+#pragma unroll
+                for (int it = 0; it < (WS ? WNIT : 1); ++it) woff[it] = woffN[it];
+                pb = pe; slot ^= 1;
+            }
+        }
+        for (;;) {
+            const int pe = (pb + nchunks) & 1;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            set_ml();
+            OAI_PSTAMP(0);
+            if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
+            else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
+            else if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+            else run_chunks(std::integral_constant<int, 1>{});
+            // (the fragments requested past the last tap: see the plain form)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]), "+v"(bq[1][1][1]),
+                         "+v"(bq[NB - 1][0][0]), "+v"(bq[NB - 1][0][1]), "+v"(bq[NB - 1][1][0]), "+v"(bq[NB - 1][1][1]) :: "memory");
+            read_ctl(slot ^ 1);                                      // (written before the barrier of chunk nchunks - 3)
+            const bool have_next = nb[5] != 0;
+            if (have_next) load_nbox();                              // (needed behind the epilogue)
+            xb = Tl + (pe ^ 1) * TB;
+            load_epilogue_consts();
+            finish_block();                                          // (requests the next block's first fragment sets and waits for them)
+            wp = wp_base + D * STEP * 16;
+            sgpr_settle(wp);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            OAI_PSTAMP(2);
+#ifdef OAI_DIAG
+            ++psblocks;
+#endif
+            if (!have_next) break;
+            set_block(nb[0], nb[1], nb[2], nb[3], nb[4], nbox);
+            pb = pe; slot ^= 1;
+        }
+#ifdef OAI_DIAG
+        if (a.stamps && wave == 0 && lane == 0) {
+            atomicAdd(a.stamps + 0, pst[0]); atomicAdd(a.stamps + 1, pst[1]); atomicAdd(a.stamps + 2, pst[2]); atomicAdd(a.stamps + 3, pst[3]);
+            atomicAdd(a.stamps + 8, psblocks);
+        }
+#endif
     } else {
-        if (f == 0) finish2(std::integral_constant<int, 0>{});
-        else if (f == 1) finish2(std::integral_constant<int, 1>{});
-        else if (f == 2) finish2(std::integral_constant<int, 2>{});
-        else finish2(std::integral_constant<int, 3>{});
+        if (stager) {
+            // WS, waves 4-7: while the multipliers run the taps of chunk ch, transform the rows of chunk ch + 1 (requested a chunk ago: the wait is
+            // short) into the other T buffer, then request chunk ch + 2 into the same rows; one barrier per chunk, the multipliers' chunk-end one
+            for (int ch = 0; ch < nchunks; ++ch) {
+                if (ch + 1 < nchunks) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!OAI_DBG_BIT(a, 16384)) stage_transform(ch + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ch + 2 < nchunks) stage_request(ch + 2);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            // the multipliers' epilogue: its four barriers per cout half, then this wave's half of the image's copy-out (the next half's first barrier
+            // waits for these LDS reads before the exchange overwrites the image)
+            int sclo[3], schi[3];
+            store_box(sclo, schi);
+    #pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+                for (int i = 0; i < 4; ++i) __syncthreads();
+                copy_out(n, EIT / 2, EIT, sclo, schi);
+            }
+            return;
+        }
+        if constexpr (MS == 1) {
+            if (ml == 4) run_chunks(std::integral_constant<int, 4>{});
+            else if (ml == 3) run_chunks(std::integral_constant<int, 3>{});
+            else if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+            else run_chunks(std::integral_constant<int, 1>{});
+        } else {
+            if (ml == 2) run_chunks(std::integral_constant<int, 2>{});
+            else if (ml == 1) run_chunks(std::integral_constant<int, 1>{});
+            else run_chunks(std::integral_constant<int, 0>{});
+        }
+
+        // fragments requested past the last tap / step: never used, but still in flight INTO their registers -- the wait names them, so that they stay
+        // allocated until it has executed (a bare wait lets the compiler reuse the "dead" registers between the loop exit and the wait: unet_sres.h)
+        if constexpr (WS && M16) {
+            if (!stager) { ws16_landed(fs[0]); ws16_landed(fs[1]); }
+        } else if constexpr (D > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]), "+v"(bq[1][1][1]),
+                         "+v"(bq[NB - 1][0][0]), "+v"(bq[NB - 1][0][1]), "+v"(bq[NB - 1][1][0]), "+v"(bq[NB - 1][1][1]) :: "memory");
+        }
+        OAI_WSTAMP(2);
+        seen = census_peek(a.census);                               // (waited for under the epilogue)
+        load_epilogue_consts();
+        finish_block();
     }
     if (nonfinite || umax > __builtin_bit_cast(unsigned, 3.0e38f)) atomicOr(a.range_flag, 1);
     census_note(a.census, a.range_flag, vmax, seen);
 #ifdef OAI_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the stamped epilogue includes the round trip of its last stores)
     OAI_WSTAMP(3);
-    if (a.stamps && lane == 0) {
+    if (!PS && a.stamps && lane == 0) {
         atomicAdd(a.stamps + 0, wst[1] - wst[0]); atomicAdd(a.stamps + 1, wst[2] - wst[1]); atomicAdd(a.stamps + 2, wst[3] - wst[2]);
         atomicAdd(a.stamps + 3, wep[0]); atomicAdd(a.stamps + 4, wep[1]); atomicAdd(a.stamps + 5, wep[2]);
         atomicAdd(a.stamps + 8, 1ull);
@@ -1095,6 +1406,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     }
 #endif
 #undef OAI_WSTAMP
+#undef OAI_PSTAMP
 #undef OAI_WEP0
 #undef OAI_WEP
 }

@@ -220,7 +220,7 @@ def test_fp16x3_reports_activations_outside_fp16_range():
 
 
 @pytest.mark.parametrize("opts", [{"sres_mrep": 2}, {"sres_ring": 1}, {"xcd_group": 0}, {"xcd_group": 7}, {"sres": 0}, {"fuse_first": 0}, {"b_lds": 1},
-                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}])
+                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}, {"persistent": 1}])
 def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     """The tuning variants of the default path (2 z slices per block, the six-slot plane ring, other XCD dealings, fp32-resident
     activations, ec0 as its own launch instead of inside ec1's halo staging, weight fragments through the workgroup's LDS ring, the
@@ -295,6 +295,25 @@ def test_mask_is_the_fp32_sigmoid_predicate_not_the_sign_test(precision):
     assert disagree >= window                 # the sign test would be wrong on the whole window
     assert differ <= int(between.sum())
     assert (mask > 0.5).any() and not (mask > 0.5).all()
+
+
+def test_persistent_workgroups_are_bit_identical():
+    """Option "persistent" (round 5): the specialised 64-cout Winograd form (dc2) with ONE workgroup per CU pulling blocks from per-XCD counters, the
+    staging waves one block ahead (conv3_wino_sres<..., PS>).  Which workgroup computes a block, and in which order, changes nothing about a block's own
+    arithmetic: the maps are bit-identical -- on a ragged volume with strips, border tiles (trimmed boxes: tiles without blocks in a launch) and several
+    batch sizes (few blocks per workgroup ... more workgroups than blocks)."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    tile, ovl, shape = (24, 40, 64), (6, 4, 8), (28, 66, 154)
+    crop = (ovl[0], ovl[2], ovl[1])
+    v = torch.from_numpy(make_volume(201, shape)).cuda()
+    eng = UNetEngine(make_unet_state_dict(seed=51, width_div=1), precision="fp16x3")
+    st = lambda b: eng.stitch(b, shape, tile, ovl, crop)
+    ref = st(eng.segment_tiles(v, tile, ovl, None, 2, 6, crop))
+    eng.set_option("persistent", 1)
+    for batch in (1, 6, 36):
+        assert torch.equal(st(eng.segment_tiles(v, tile, ovl, None, 2, batch, crop)), ref), batch
+    eng.set_option("persistent", 0)
+    assert torch.equal(st(eng.segment_tiles(v, tile, ovl, None, 2, 6, crop)), ref)
 
 
 @pytest.mark.parametrize("wino", [19, 51])
