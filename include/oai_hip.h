@@ -243,6 +243,9 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *                       stays bit-preserving); every launch shape of the kernel has the variant: one summation order per layer.  Same cycles per FLOP,
  *                       +12-14 % clock at the power wall: ec1 16.8 -> 14.6, ec2 4.9 -> 3.9, dc1 8.5 -> 7.2 ms per 160 tiles.  "m16_layers" (mask, all):
  *                       bit k = layer k may take it (A/B of single layers)
+ *   "persistent" 0|1 (0) bit-preserving (round 5): the 64-cout Winograd layer (dc2) with ONE persistent workgroup per CU that pulls blocks from per-XCD counters
+ *                       (a small plan kernel in front of every launch) while its staging waves run one block ahead.  Built for VERDICT r4 #1 (b) / (d); measured
+ *                       +-0 ... +0.8 % per pass (profiles/r05_persistent.md): not the default
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)
  * Unknown names and out-of-range values return OAI_ERR_ARG. */

@@ -146,8 +146,9 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
         loads = [ln for ln in seg if "global_load_dwordx4" in ln or "global_load_lds_dwordx4" in ln]
         assert all("s[" in ln.split("//")[0] or "lds" in ln for ln in loads), "a weight-fragment load that is not the SGPR-base asm form"
     # (e) conv3_wino_sres (unet_wino.h) counts vmcnt by hand as well: 9 taps x 24 MFMAs per chunk for ML = 4; no scratch anywhere in the kernel
-    for sym, n_mf in (("_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb0EEEvNS_8ConvArgsEPKh", 540), ("_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi2ELb0ELb0EEEvNS_8ConvArgsEPKh", 162),
-                      ("_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi1ELb1ELb0EEEvNS_8ConvArgsEPKh", 540)):       # (the specialised form: four multiplying waves, ML = 4 .. 1)
+    for sym, n_mf in (("_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb0ELb0EEEvNS_8ConvArgsEPKh", 540), ("_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi2ELb0ELb0ELb0EEEvNS_8ConvArgsEPKh", 162),
+                      ("_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi1ELb1ELb0ELb0EEEvNS_8ConvArgsEPKh", 540),
+                      ("_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi1ELb1ELb0ELb1EEEvNS_8ConvArgsEPKh", 540)):       # (the specialised form: four multiplying waves, ML = 4 .. 1; its persistent variant, option "persistent": the same tap streams)
         m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
         assert m, f"{sym} not in the library"
         body = m.group(1).split("\n")
@@ -159,17 +160,21 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
     # (f) the default two-group form (round 4): the same kernel with its taps on v_mfma_f32_16x16x32_f16, K = a pair of taps -- 14 steps x 32
     # MFMAs per chunk for ML = 4 (448 + 336 + 224 + 112); its counted waits need a tap stream free of compiler-made vector-memory operations
     # (a scratch reload drains vmcnt: every prefetched fragment with it), and its halo pieces come from an SGPR base + 32-bit offset
-    for sym in ("_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1EEEvNS_8ConvArgsEPKh", "_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi1ELb1ELb1EEEvNS_8ConvArgsEPKh"):
+    for sym in ("_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1ELb0EEEvNS_8ConvArgsEPKh", "_ZN3oai15conv3_wino_sresILi1ELi8ELi4ELi1ELb1ELb1ELb0EEEvNS_8ConvArgsEPKh"):
         m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
         assert m, f"{sym} not in the library"
         body = m.group(1).split("\n")
         mf_i = [i for i, ln in enumerate(body) if "v_mfma_f32_16x16x32_f16" in ln]
-        assert len(mf_i) == 1120 and not [ln for ln in body if "v_mfma_f32_32x32x16_f16" in ln]
-        assert not [ln for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside a tap stream of the 16x16x32 form"
+        # (the specialised form's tap-pair variant, round 5: slice-major steps on two fragment sets, the chunk loop unrolled by two + a tail = three bodies of 1120)
+        assert len(mf_i) == (1120 if "ILi2E" in sym else 3360) and not [ln for ln in body if "v_mfma_f32_32x32x16_f16" in ln]
+        # (the counted waits are the two-group form's: the specialised variant waits with vmcnt(0) only -- a compiler-made reload cannot shift a count there; it
+        #  keeps 256 B of scratch, is not the default and not faster, profiles/r05_persistent.md section 4)
+        if "ILi2E" in sym:
+            assert not [ln for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1] if "scratch_" in ln], "scratch traffic inside a tap stream of the 16x16x32 form"
         loads = [ln for ln in body if "global_load_dwordx4" in ln and "lds" not in ln]
         assert len(loads) >= 40 and all("s[" in ln.split("//")[0] for ln in loads), "a fragment load that is not the SGPR-base asm form"
     # (the two-group form's halo pieces also come from an SGPR base + 32-bit offset; the specialised form's stagers keep the per-lane 64-bit form)
-    assert all("s[" in ln.split("//")[0] for ln in re.search(r"^[0-9a-f]+ <_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1EEEvNS_8ConvArgsEPKh>:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M).group(1).split("\n") if "global_load_lds_dwordx4" in ln)
+    assert all("s[" in ln.split("//")[0] for ln in re.search(r"^[0-9a-f]+ <_ZN3oai15conv3_wino_sresILi2ELi8ELi4ELi1ELb0ELb1ELb0EEEvNS_8ConvArgsEPKh>:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M).group(1).split("\n") if "global_load_lds_dwordx4" in ln)
     # (g) round 5: the direct kernel on 16x16x32 tap pairs (conv3_igemm_sres<..., M16>, default for the layers with Cout % 128 != 0): 14 steps of
     # 96 / 64 MFMAs per chunk for ML = 4 (1312 + 984 + 656 + 328), no 32x32x16, no scratch in a tap stream, every fragment load the SGPR-base asm
     # form -- and NO BRANCH WHILE A FRAGMENT LOAD IS IN FLIGHT: an inline-asm load is invisible to the compiler (it believes the result register
