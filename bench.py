@@ -330,6 +330,7 @@ def streamed_from_host(pipe, n_volumes=24, resident_ms=None):
                             "into_pinned_GBps": st["stage_bytes"] / st["stage_s"] / 1e9 if st["stage_s"] else None,
                             "bytes_per_volume": (st["clone_bytes"] + st["stage_bytes"]) / max(n, 1),
                             "launch_thread_waited_s": st["launch_wait_s"],
+                            "launch_thread_s": {k: round(st[k], 4) for k in ("t_upload_wait", "t_queue_compute", "t_issue_d2h", "t_result_wait") if k in st},
                             "note": "both copies run on worker threads (cohort.py); the launch thread only queues work"},
             "what": f"{n} volumes from pageable host arrays -> pinned staging -> H2D -> segment + register + resample -> D2H of fc, tc, phi, "
                     "fc_atlas, tc_atlas (566 MB per volume) -> caller-owned host tensors; upload / compute / download / host copy overlapped (cohort.CohortRunner)"}
