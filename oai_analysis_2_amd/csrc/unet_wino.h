@@ -75,7 +75,9 @@ namespace oai {
 // multipliers go from a block's epilogue straight into the next block's taps -- no prologue (request, L2 / HBM round trip, transform: ~5 us of a ~70-us
 // block) and no workgroup launch in between (~4 us of an idle CU per block: profiles/r04_wino_stream.md section 6).  Same arithmetic, same order: bit-identical.
 template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false, bool PS = false>
-__global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+// (-DOAI_EXP bit 64, timing only, results WRONG: the four-wave form <1, TY, NP, 1> as TWO independent workgroups per CU -- its raw box aliased onto half the bytes so that
+//  a workgroup fits 80 KB of LDS; same DMA instructions, same traffic, same transform and tap work: does a second, unsynchronised workgroup fill what one leaves empty?)
+__global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && NG * MS == 1 && !WS) ? 2 : 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     static_assert(!PS || (WS && !M16), "persistent workgroups: the specialised form");
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
@@ -87,7 +89,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
     constexpr int NIT = (PIECES + NT - 1) / NT;                   // LDS-DMA instructions per thread per chunk: 5 (NG 2) / 10 (NG 1) for 8 x 4
     constexpr int TB = HZ * 4 * HY * NP * 64;                     // 61 440 bytes of T for 8 x 4
     constexpr int RPW = HZ * HY / 4, WNIT = (RPW * RS + 63) / 64;    // WS: halo rows and LDS-DMA instructions per staging wave and chunk (15, 10)
-    constexpr int RAWB = WS ? 4 * WNIT * 1024 : NIT * NT * 16;    // 40 960 bytes of raw box (whole 1-KiB wave writes)
+    constexpr bool kHalfRaw = (OAI_EXP & 64) && NG * MS == 1 && !WS;
+    constexpr int RAWB = WS ? 4 * WNIT * 1024 : kHalfRaw ? NIT * NT * 16 / 2 : NIT * NT * 16;    // 40 960 bytes of raw box (whole 1-KiB wave writes)
+    auto rawo = [](int o) constexpr { return kHalfRaw ? o % RAWB : o; };       // (OAI_EXP 64: byte offsets inside the raw box wrap)
     constexpr int UNITS = HZ * 2 * HY * NP;                       // 480 transform units (hz, half, hy, pair)
     constexpr int XB = 3 * 4 * 4 * 1024;                          // exchange buffer of one cout group: [f][3 slices][4 row groups][lane] x 16 B
     static_assert(NG == 1 || NG == 2, "one or two cout groups");
@@ -196,7 +200,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         const bool first = ch < nch0;
         const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
         const unsigned char* g = (real && poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + poff[it] : zero_rec;
-        lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16));
+        lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + rawo((it * NT + wave * 64) * 16)));
     };
     // M16: the piece from a wave-uniform base (SGPR pair) + a 32-bit per-lane offset -- no 64-bit per-lane address, no select against the zero
     // record (hoisted out of the chunk loop those are ten more registers; spilled, their reload inside the taps drains vmcnt).  A piece outside
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         const unsigned off = poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072) ? poff[it] : 0u;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(cbase), "s"(__builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16)) : "memory");
+                     : "=&s"(keep) : "v"(off), "s"(cbase), "s"(__builtin_amdgcn_readfirstlane(raw0 + rawo((it * NT + wave * 64) * 16))) : "memory");
     };
     unsigned miss = 0;                                              // bit it: piece it of this thread lies outside the tile
     if constexpr (M16 && !WS) {
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
         if (__builtin_amdgcn_ballot_w64(miss != 0) == 0) return;     // (interior blocks: no wave has one)
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-            if (miss & (1u << it)) *reinterpret_cast<float4*>(raw + (it * NT + tid) * 16) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (miss & (1u << it)) *reinterpret_cast<float4*>(raw + rawo((it * NT + tid) * 16)) = float4{0.0f, 0.0f, 0.0f, 0.0f};
     };
     // pieces requested in tap t (for the NEXT chunk): spread over the nine taps, the early taps take the remainder
     auto pieces_in_tap = [](int t) constexpr { return WS ? 0 : NIT / 9 + (t < NIT % 9 ? 1 : 0); };
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 int t = u / NP;
                 const int hy = t % HY; t /= HY;
                 const int hf = t & 1, hz = t >> 1;
-                transform_unit(raw + (((hz * HY + hy) * RS) + 4 * p + hf) * 16, hz, hy, p, hf, Tl);
+                transform_unit(raw + (kHalfRaw ? ((((hz * HY + hy) * RS) + 4 * p + hf) * 16) % (RAWB - 1024) : (((hz * HY + hy) * RS) + 4 * p + hf) * 16), hz, hy, p, hf, Tl);      // (OAI_EXP 64: the unit's 4 x 2 pieces stay inside the box)
             }
         }
     };
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 // pieces of the NEXT chunk's raw box: requested at the ends of steps 0..3 (step 4 requests nothing: what the chunk-end wait covers was
                 // requested at least one step -- 96 MFMAs -- earlier)
                 auto np_of = [](int j) constexpr { int c = 0; for (int q = 0; q < NIT; ++q) c += (j < 4 && q % 4 == j) ? 1 : 0; return c; };
-                static_assert(NIT >= 4 && NIT <= 8, "one or two pieces per step 0..3 (the waits below name 1 or 2)");
+                static_assert(NIT >= 4 && NIT <= 12, "one to three pieces per step 0..3 (the waits below name 1, 2 or 3)");
                 float4 af[MREP][2];                                     // [m][p]: the A fragments of the running pass
 #pragma unroll
                 for (int m = 0; m < ML; ++m)
@@ -587,7 +591,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                 for (int j = 0; j < 5; ++j) {
                         // vector-memory operations younger than Y'(j) at the top of step j: lo(j), hi(j) and the pieces requested at the end of step j - 1
                     const int npp = j > 0 ? np_of(j - 1) : 0;           // (step 0: the fragments were requested at the chunk's top, nothing behind them)
-                    if (npp == 0) vm_wait<4>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<6>(bY[0], bY[1], bY[2], bY[3]);
+                    if (npp == 0) vm_wait<4>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 2) vm_wait<6>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<7>(bY[0], bY[1], bY[2], bY[3]);
                     __builtin_amdgcn_sched_barrier(0);
                     // pass B: a0 . Y'  (step 4: [a0 | a1] . [b1 | 0])
 #pragma unroll
@@ -605,7 +609,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                     {
                         constexpr int kD2 = 0; (void)kD2;
                         const int y = 2 + npp + (j < 4 ? 4 : 0);
-                        if (y == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        if (y == 9) asm volatile("s_waitcnt vmcnt(9)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        else if (y == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
+                        else if (y == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
                         else if (y == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
                         else if (y == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
                         else if (y == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(bXlo[0]), "+v"(bXlo[1]) :: "memory");
@@ -624,7 +630,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(c
                     // hi(j) has landed; younger: pieces(j - 1), Y'(j + 1)
                     {
                         const int y = npp + (j < 4 ? 4 : 0);
-                        if (y == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        if (y == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        else if (y == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
+                        else if (y == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
                         else if (y == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
                         else if (y == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
                         else if (y == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(bXhi[0]), "+v"(bXhi[1]) :: "memory");
