@@ -1221,6 +1221,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         // this lane's four column scales / shifts, loaded ONCE here: inside the loops below hipcc waits for them with vmcnt(0), which in
         // the second half also drains the first half's sixteen copy-out stores all the way to memory
         const unsigned seen = census_peek(a.census);
+        unsigned umax = 0;
         float scn[4], shn[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -1241,27 +1242,34 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     vmask |= (vtab[wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] != ~0u ? 1u : 0u) << r;
+                const bool odd = row & 1;
+                const unsigned sel = odd ? 0x03020706u : 0x05040100u;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const int col = ncol0 + n * 32 + row;
-                    const bool cok = col < N;
                     const float sc = scn[n], sh = shn[n];
-                    const bool odd = row & 1;
-                    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-                    unsigned char* lrow = ulds + ((wn * 128 + n * 32 + row) >> 4) * 64 + ((row & 15) >> 1) * 4;
+                    // (round 5: 1 700 VALU operations of this epilogue stood against 192 MFMAs of dc3's k loop; the per-value tests are gone -- the ReLU a plain max,
+                    //  the row / column tests one mask word applied by v_bfe_i32 + v_and, the census maximum on bit patterns: 1 444 operations, same values bit
+                    //  for bit -- and the up-convs' time did not move (same-box A/B 127.3-128.0 ms per pass either way): vector issue is not their bound either)
+                    unsigned om = col < N ? vmask : 0u;
+                    asm volatile("" : "+v"(om));
+                    // this lane's image row of element (r, e = odd): voxel row (r + odd) & 3 + 8 (r >> 2) + 4 half -- r is even: + odd
+                    unsigned char* lrow = ulds + ((wn * 128 + n * 32 + row) >> 4) * 64 + ((row & 15) >> 1) * 4 + (wm * 32 + 4 * half + (odd ? 1 : 0)) * 1024;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         float v[2];
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            float x = acc[m][n][r + e] * sc + sh;
-                            if (a.relu) x = fmaxf(x, 0.0f);
-                            v[e] = (cok && ((vmask >> (r + e)) & 1u)) ? x : 0.0f;      // rows outside the box read unwritten memory
+                            const float x = fmaxf(acc[m][n][r + e] * sc + sh, 0.0f);                   // (ConvTranspose3d [+ BN] + ReLU: networks.py:94-107; launch_up launches no other form)
+                            unsigned keep;                                     // 0 or ~0: rows outside the box read unwritten memory (as asm: the builtin is folded back into a compare + select)
+                            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(om), "n"(r + e));
+                            v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & keep);
                         }
-                        vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                        // (behind the ReLU every value is >= +0: the largest |v| is the largest BIT PATTERN -- one v_max3_u32 per pair)
+                        umax = max(umax, max(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])));
                         unsigned w_hi, w_lo;
                         split_two_voxels(v[0], v[1], sel, w_hi, w_lo);
-                        const int vl = wm * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2) + 4 * half;
+                        const int vl = (r & 3) + 8 * (r >> 2);
                         *reinterpret_cast<unsigned*>(lrow + vl * 1024) = w_hi;
                         *reinterpret_cast<unsigned*>(lrow + vl * 1024 + 32) = w_lo;
                     }
@@ -1279,6 +1287,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             }
             OAI_USTAMP(4);
         }
+        vmax = __builtin_bit_cast(float, umax);
         census_note(a.census, a.range_flag, vmax, seen);
 #ifdef OAI_DIAG
         OAI_USTAMP(4);
