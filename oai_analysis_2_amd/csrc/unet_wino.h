@@ -575,7 +575,10 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                 auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
                     return *reinterpret_cast<const float4*>(Tl + off + m * SL + p * 1024);
                 };
+                bool exp_skip = false;                                  // (-DOAI_EXP bit 128, timing only: step 2 of every chunk without its 96 MFMAs -- every weight-fragment load, halo piece and wait kept:
+                //                                                         what does a pass cost per MFMA at the power wall?  profiles/r05_persistent.md section 6)
                 auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
+                    if ((OAI_EXP & 128) && exp_skip) return;
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
                 };
                 // pieces of the NEXT chunk's raw box: requested at the ends of steps 0..3 (step 4 requests nothing: what the chunk-end wait covers was
@@ -590,6 +593,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                         // vector-memory operations younger than Y'(j) at the top of step j: lo(j), hi(j) and the pieces requested at the end of step j - 1
+                    exp_skip = j == 2;
                     const int npp = j > 0 ? np_of(j - 1) : 0;           // (step 0: the fragments were requested at the chunk's top, nothing behind them)
                     if (npp == 0) vm_wait<4>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 2) vm_wait<6>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<7>(bY[0], bY[1], bY[2], bY[3]);
                     __builtin_amdgcn_sched_barrier(0);
