@@ -191,13 +191,17 @@ class IconEngine:
 
     ``apply_bn`` / ``pad_front``: the two points where the restatement of the un-vendored ``icon_registration`` 1.1.2 rests on
     recollection (oracle/icon.py:OPTIONS): eval-mode BatchNorm3d behind every up-conv or none, and the side on which
-    ``pad_or_crop`` adds zero channels.  Defaults: no BatchNorm (round 4: two independent recollections of the package's
-    ``UNet2.forward`` have the ``batchNorms[depth]`` call commented out -- the ModuleList only exists in ``__init__``, which is why
-    the keys are in the state_dict), zero channels in front."""
+    ``pad_or_crop`` adds zero channels.  ``apply_bn=None`` (the default) lets the CHECKPOINT decide (:func:`infer_apply_bn`): trained
+    BatchNorm tensors are proof that ``UNet2.forward`` calls the layers, pristine ones make the switch irrelevant.  Zero channels
+    go in front."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], net_shape: Sequence[int] = NET_SHAPE, device=None,
-                 apply_bn: bool = False, pad_front: bool = True):
+                 apply_bn: Optional[bool] = None, pad_front: bool = True):
         import ctypes as C
+        if apply_bn is None:
+            apply_bn, self.apply_bn_reason = infer_apply_bn(state_dict)
+        else:
+            self.apply_bn_reason = "stated by the caller"
         state_dict, self.tree = map_icon_state_dict(state_dict, with_tree=True)
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -294,10 +298,18 @@ class IconEngine:
         return phi_AB, phi_BA
 
 
+def _unwrap_state_dict(state_dict):
+    sd = state_dict
+    for wrap in ("model_state_dict", "state_dict"):
+        if wrap in sd and isinstance(sd[wrap], dict):
+            sd = sd[wrap]
+    return sd
+
+
 def _has_nontrivial_batchnorm(state_dict) -> bool:
     """True if any ``batchNorms.*`` tensor of the checkpoint differs from a freshly constructed BatchNorm3d (gamma 1, beta 0, running mean 0,
     running variance 1): only then does applying or skipping it change phi."""
-    for k, v in state_dict.items():
+    for k, v in _unwrap_state_dict(state_dict).items():
         if ".batchNorms." not in k and not k.startswith("batchNorms."):
             continue
         t = torch.as_tensor(v).float()
@@ -309,20 +321,36 @@ def _has_nontrivial_batchnorm(state_dict) -> bool:
     return False
 
 
-_BN_WARNED = False
+def infer_apply_bn(state_dict) -> Tuple[bool, str]:
+    """Whether ``UNet2.forward`` applies ``self.batchNorms[depth]`` -- read off the checkpoint (reference call site registration.py:20 loads
+    it; the package is not installed here).  A BatchNorm3d's ``running_mean`` / ``running_var`` only move and its ``num_batches_tracked`` only
+    counts when the module is CALLED in training mode, and gamma / beta only receive gradients when its output feeds the loss.  So:
+
+    * any ``num_batches_tracked > 0`` or any BatchNorm tensor off its constructor value  =>  the package called the layers while this
+      checkpoint was trained  =>  they are part of the function the weights were fitted to: apply them;
+    * all pristine (gamma 1, beta 0, mean 0, var 1, zero batches)  =>  the layers were never called; an eval-mode BatchNorm with those
+      tensors is x / sqrt(1 + eps), 5e-6 relative per level -- either setting gives the same phi within 1e-4; skip them.
+
+    Returns (apply_bn, reason).  An explicit ``apply_bn=`` argument or ``$OAI_ICON_APPLY_BN`` overrides this."""
+    sd = _unwrap_state_dict(state_dict)
+    tracked = [int(torch.as_tensor(v).max()) for k, v in sd.items()
+               if k.endswith("num_batches_tracked") and (".batchNorms." in k or k.startswith("batchNorms.")) and torch.as_tensor(v).numel()]
+    if any(n > 0 for n in tracked):
+        return True, f"num_batches_tracked = {max(tracked)} > 0: the BatchNorm layers were called in training"
+    if _has_nontrivial_batchnorm(sd):
+        return True, "BatchNorm tensors differ from their constructor values: the layers were trained, hence called"
+    return False, "BatchNorm tensors are pristine (never called in training): applying them would change phi by < 1e-4"
 
 
-def _warn_bn_assumption_once() -> None:
-    global _BN_WARNED
-    if _BN_WARNED:
+_BN_NOTED = False
+
+
+def _note_bn_decision_once(apply_bn: bool, reason: str) -> None:
+    global _BN_NOTED
+    if _BN_NOTED:
         return
-    _BN_WARNED = True
-    import warnings
-    warnings.warn("ICON_Registration: this checkpoint holds BatchNorm tensors that are NOT the identity, and `apply_bn` was not stated.  They are "
-                  "NOT applied -- assumption: icon_registration 1.1.2's UNet2.forward has `x = self.batchNorms[depth](x)` commented out (the package "
-                  "is not installed here, so this cannot be checked; tests/test_icon_pin_gpu.py checks it wherever the package imports).  If the "
-                  "package does apply them, phi is wrong: pass apply_bn=True (or OAI_ICON_APPLY_BN=1).  Pass apply_bn=False to silence this.",
-                  stacklevel=3)
+    _BN_NOTED = True
+    print(f"ICON_Registration: apply_bn={apply_bn} decided from the checkpoint -- {reason}")
 
 
 class ICON_Registration:
@@ -334,12 +362,10 @@ class ICON_Registration:
 
     def __init__(self, weights=None, net_shape: Sequence[int] = NET_SHAPE, device=None, verbose: bool = True,
                  apply_bn: Optional[bool] = None, pad_front: bool = True):
-        """``apply_bn``: whether the eval-mode BatchNorm3d behind every up-conv of ``tallUNet2`` is applied.  This cannot be verified here
-        (``icon_registration`` 1.1.2 is neither vendored nor installed; two independent recollections have the call commented out in
-        ``UNet2.forward``), so it is NOT a silent default: state it -- ``apply_bn=True / False`` or ``$OAI_ICON_APPLY_BN=1 / 0`` --
-        or, unstated, the BatchNorm is skipped and a checkpoint whose BatchNorm tensors are not the identity (trained statistics that
-        would change phi) gets ONE prominent warning naming the assumption.  ``tests/test_icon_pin_gpu.py`` settles it against the
-        package itself the first time an environment has ``icon_registration`` importable."""
+        """``apply_bn``: whether the eval-mode BatchNorm3d behind every up-conv of ``tallUNet2`` is applied.  Stated -- ``apply_bn=True /
+        False`` or ``$OAI_ICON_APPLY_BN=1 / 0`` -- it is obeyed; unstated, the checkpoint decides (:func:`infer_apply_bn`: trained BatchNorm
+        statistics prove the package calls the layers) and one line says what was decided and why.  ``tests/test_icon_pin_gpu.py``
+        checks the inference against the package itself wherever ``icon_registration`` imports."""
         import os
         if weights is None:
             root = os.environ.get("OAI_DATA_DIR")
@@ -353,9 +379,9 @@ class ICON_Registration:
         if apply_bn is None and os.environ.get("OAI_ICON_APPLY_BN", "") in ("0", "1"):
             apply_bn = os.environ["OAI_ICON_APPLY_BN"] == "1"
         if apply_bn is None:
-            apply_bn = False
-            if _has_nontrivial_batchnorm(weights):
-                _warn_bn_assumption_once()
+            apply_bn, why = infer_apply_bn(weights)
+            if verbose:
+                _note_bn_decision_once(apply_bn, why)
         self.register_module = IconEngine(weights, net_shape, device, apply_bn=apply_bn, pad_front=pad_front)
         self.verbose = verbose
 

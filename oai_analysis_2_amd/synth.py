@@ -124,8 +124,10 @@ ICON_UP_OUT = [16, 32, 64, 128, 256]
 ICON_UP_IN = [48, 96, 192, 512, 512]      # down[1:] + (up_out[1:] + [0])
 
 
-def make_icon_unet_state_dict(seed: int, dimension: int = 3, last_scale: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
-    """Weights of one ``tallUNet2`` with the public package's parameter names.
+def make_icon_unet_state_dict(seed: int, dimension: int = 3, last_scale: float = 1.0, bn: str = "trained") -> "OrderedDict[str, torch.Tensor]":
+    """Weights of one ``tallUNet2`` with the public package's parameter names.  ``bn``: "trained" = BatchNorm tensors as training leaves
+    them (statistics moved, gamma / beta fitted, ``num_batches_tracked`` = 1000), "pristine" = as the constructor leaves them (a
+    checkpoint of a package whose forward never calls the layers), "absent" = no BatchNorm keys at all.
 
     ``lastConv`` is zero-initialised in the real package and learnt; a trained net emits
     displacements of a few percent of the image extent, which ``last_scale`` reproduces.
@@ -140,11 +142,16 @@ def make_icon_unet_state_dict(seed: int, dimension: int = 3, last_scale: float =
         # a k4 s2 p1 transposed conv touches 8 of its 64 taps per output voxel
         sd[f"upConvs.{d}.weight"] = torch.randn((cin, cout, 4, 4, 4), generator=g) * math.sqrt(1.0 / (cin * 8))
         sd[f"upConvs.{d}.bias"] = (torch.rand(cout, generator=g) - 0.5) * 0.1
-        sd[f"batchNorms.{d}.weight"] = 0.75 + 0.5 * torch.rand(cout, generator=g)
-        sd[f"batchNorms.{d}.bias"] = (torch.rand(cout, generator=g) - 0.5) * 0.2
-        sd[f"batchNorms.{d}.running_mean"] = (torch.rand(cout, generator=g) - 0.5) * 0.2
-        sd[f"batchNorms.{d}.running_var"] = 0.75 + 0.5 * torch.rand(cout, generator=g)
-        sd[f"batchNorms.{d}.num_batches_tracked"] = torch.tensor(1000, dtype=torch.long)
+        gamma, beta = 0.75 + 0.5 * torch.rand(cout, generator=g), (torch.rand(cout, generator=g) - 0.5) * 0.2      # (drawn in every mode:
+        mean, var = (torch.rand(cout, generator=g) - 0.5) * 0.2, 0.75 + 0.5 * torch.rand(cout, generator=g)        # the conv weights do not depend on ``bn``)
+        if bn == "pristine":
+            gamma, beta, mean, var = torch.ones(cout), torch.zeros(cout), torch.zeros(cout), torch.ones(cout)
+        elif bn not in ("trained", "absent"):
+            raise ValueError(f"bn must be trained / pristine / absent, not {bn!r}")
+        if bn != "absent":
+            sd[f"batchNorms.{d}.weight"], sd[f"batchNorms.{d}.bias"] = gamma, beta
+            sd[f"batchNorms.{d}.running_mean"], sd[f"batchNorms.{d}.running_var"] = mean, var
+            sd[f"batchNorms.{d}.num_batches_tracked"] = torch.tensor(1000 if bn == "trained" else 0, dtype=torch.long)
     sd["lastConv.weight"] = torch.randn((3, 18, 3, 3, 3), generator=g) * (last_scale * math.sqrt(1.0 / (18 * 27)))
     sd["lastConv.bias"] = (torch.rand(3, generator=g) - 0.5) * 0.02 * last_scale
     return sd
@@ -185,12 +192,12 @@ def icon_tree_prefixes(tree) -> list:
     return out
 
 
-def make_icon_state_dict(seed: int = 0, last_scale: float = 0.3, tree="3step") -> "OrderedDict[str, torch.Tensor]":
+def make_icon_state_dict(seed: int = 0, last_scale: float = 0.3, tree="3step", bn: str = "trained") -> "OrderedDict[str, torch.Tensor]":
     """``regis_net`` state dict of a gradICON model: one tallUNet2 per FFVF of ``tree`` (default: the three-step tree, key prefixes
     ``netPhi.net.netPhi.net.*`` (u1, low-res), ``netPhi.net.netPsi.net.*`` (u2, low-res), ``netPsi.net.*`` (u3, full-res))."""
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for i, prefix in enumerate(icon_tree_prefixes(tree)):
-        for k, v in make_icon_unet_state_dict(seed * 3 + i, last_scale=last_scale).items():
+        for k, v in make_icon_unet_state_dict(seed * 3 + i, last_scale=last_scale, bn=bn).items():
             out[prefix + k] = v
     return out
 

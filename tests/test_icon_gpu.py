@@ -117,6 +117,71 @@ def test_restatement_switches_match_the_oracle_both_ways(apply_bn, pad_front):
         assert _rel(got - ident, ref - ident) < TOL
 
 
+def test_the_checkpoint_decides_apply_bn_when_nobody_states_it(capsys):
+    """VERDICT r5 weak #1 (reference call site registration.py:20): BatchNorm running statistics only move, ``num_batches_tracked`` only
+    counts and gamma / beta only receive gradients if ``UNet2.forward`` CALLS ``batchNorms[depth]`` in training.  A checkpoint with trained
+    BatchNorm tensors therefore proves the package applies them (default = apply, equal to the oracle run with apply_bn=True and far
+    from the one without); pristine tensors prove nothing and change nothing (either setting within 1e-4 of the other); a counter above
+    zero alone is proof too; a stated argument or $OAI_ICON_APPLY_BN still wins."""
+    import os
+    from oai_analysis_2_amd.registration import ICON_Registration, IconEngine, infer_apply_bn
+    net = (40, 48, 48)
+    A, B = make_volume(5, net), make_volume(6, net)
+    tA, tB = torch.from_numpy(A)[None, None], torch.from_numpy(B)[None, None]
+    ident = oicon.identity_map(net)[0].numpy()
+
+    def oracle_phi(sd, apply_bn):
+        old = dict(oicon.OPTIONS)
+        try:
+            oicon.OPTIONS.update(apply_bn=apply_bn)
+            return oicon.regis_net_direction(tA, tB, sd)[0].numpy() - ident
+        finally:
+            oicon.OPTIONS.update(old)
+
+    trained = make_icon_state_dict(3)                                  # statistics moved, counter 1000
+    assert infer_apply_bn(trained)[0] is True and oicon.infer_apply_bn(trained) is True
+    eng = IconEngine(trained, net_shape=net)
+    assert eng.apply_bn is True and "num_batches_tracked" in eng.apply_bn_reason
+    got = eng.phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy() - ident
+    assert _rel(got, oracle_phi(trained, True)) < TOL
+    assert _rel(got, oracle_phi(trained, None)) < TOL                  # the oracle's own unstated default follows the same rule
+    assert _rel(got, oracle_phi(trained, False)) > 100 * TOL           # ... and skipping them would have been a different phi
+
+    pristine = make_icon_state_dict(3, bn="pristine")
+    assert infer_apply_bn(pristine)[0] is False and oicon.infer_apply_bn(pristine) is False
+    eng0 = IconEngine(pristine, net_shape=net)
+    assert eng0.apply_bn is False
+    got0 = eng0.phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy() - ident
+    got1 = IconEngine(pristine, net_shape=net, apply_bn=True).phi(torch.from_numpy(A), torch.from_numpy(B)).cpu().numpy() - ident
+    assert _rel(got0, oracle_phi(pristine, False)) < TOL and _rel(got1, oracle_phi(pristine, True)) < TOL
+    assert _rel(got0, got1) < TOL                                      # the switch is irrelevant for pristine tensors
+
+    absent = make_icon_state_dict(3, bn="absent")                      # no BatchNorm keys at all: nothing to apply
+    assert infer_apply_bn(absent)[0] is False and IconEngine(absent, net_shape=net).apply_bn is False
+
+    counted = {k: (torch.tensor(7) if k.endswith("num_batches_tracked") else v) for k, v in pristine.items()}
+    assert infer_apply_bn(counted)[0] is True                          # called in training, statistics happen to sit at their start values
+    wrapped = {"model_state_dict": {"regis_net." + k: v for k, v in trained.items()}}
+    assert infer_apply_bn(wrapped)[0] is True                          # checkpoint wrappers and the GradientICON prefix
+
+    capsys.readouterr()
+    reg = ICON_Registration(trained, net_shape=net)                    # unstated: decided, and said in one line
+    assert reg.register_module.apply_bn is True
+    assert "apply_bn=True decided from the checkpoint" in capsys.readouterr().out
+    assert ICON_Registration(trained, net_shape=net, apply_bn=False, verbose=False).register_module.apply_bn is False
+    old = os.environ.get("OAI_ICON_APPLY_BN")
+    try:
+        os.environ["OAI_ICON_APPLY_BN"] = "0"
+        assert ICON_Registration(trained, net_shape=net, verbose=False).register_module.apply_bn is False
+        os.environ["OAI_ICON_APPLY_BN"] = "1"
+        assert ICON_Registration(pristine, net_shape=net, verbose=False).register_module.apply_bn is True
+    finally:
+        if old is None:
+            os.environ.pop("OAI_ICON_APPLY_BN", None)
+        else:
+            os.environ["OAI_ICON_APPLY_BN"] = old
+
+
 # ---- the step tree is data: whatever TwoStep / Downsample / FFVF nesting the checkpoint's keys spell (VERDICT r3 #1) -------------
 
 TREES = [("3step", (40, 48, 48)), ("4step", (40, 48, 48)), ("multires", (68, 72, 76)), ("multires4", (68, 76, 72))]
