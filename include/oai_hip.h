@@ -248,6 +248,9 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *                       +-0 ... +0.8 % per pass (profiles/r05_persistent.md): not the default
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)
+ *   "calibrated" 0      forget that the activation exponents were calibrated (they keep their values): oai_unet_get_act_exponents reports 0 until
+ *                       oai_unet_set_act_exponents or a settled oai_unet_calibrate_step.  For a caller that found its calibration unfit for the data
+ *                       (three flagged volumes in a row under a sidecar file): ONE place holds "calibrated?" -- this handle.  Only 0 is accepted
  * Unknown names and out-of-range values return OAI_ERR_ARG. */
 int oai_unet_set_option(oai_unet* h, const char* name, int value);
 

@@ -41,9 +41,12 @@ class CohortRunner:
     LAG = 2
     N_OUT_SETS = LAG + 1           # pinned result sets: one per volume whose download may be in flight or being emptied
 
-    def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False, high_priority_compute: bool = False):
+    def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False, high_priority_compute: bool = False, board=None):
         self.pipe = pipeline
         self.keep_on_device = keep_on_device
+        # parallel.CalibrationBoard of a multi-rank cohort (process_cohort): when a sidecar's fp16x3 calibration is dropped for not fitting the
+        # data, ONE rank recalibrates and every rank takes that outcome -- polled before each volume is queued, never a blocking collective
+        self.board = board
         # What is left between the streamed and the resident rate (2-3 %): the runtime executes a D2H into pinned memory as a copy KERNEL on the
         # compute units (`__amd_rocclr_copyBuffer` in the kernel trace of scripts/trace_cohort.py; the memory-copy trace holds no D2H entry), 7 ms
         # per volume underneath the next volume's first kernels.  `high_priority_compute` queues the volumes' kernels on a high-priority stream
@@ -164,7 +167,7 @@ class CohortRunner:
             done.synchronize()
             if res.overflow is not None:
                 raised = bool(int(res.overflow.item()))
-                self.pipe.unet.note_volume_flag(raised)
+                self._note_flag(raised, dev, cs)
                 if raised:
                     with torch.cuda.stream(cs):
                         res = self.pipe.rerun_f32(dev, img)
@@ -174,7 +177,7 @@ class CohortRunner:
             return res
         out = fut.result()
         if res.overflow is not None:
-            self.pipe.unet.note_volume_flag(out is None)
+            self._note_flag(out is None, dev, cs)
         if out is None:
             with torch.cuda.stream(cs):
                 res = self.pipe.rerun_f32(dev, img)
@@ -182,6 +185,14 @@ class CohortRunner:
                 done.record(cs)
             out = self._download_async(res, done).result()
         return out
+
+    def _note_flag(self, raised: bool, dev: torch.Tensor, cs) -> None:
+        """Streak bookkeeping of the fp16x3 range flag; when it drops a calibration FILE and the cohort has a board, the ranks agree on one
+        recalibration now (this rank calibrates on the volume it holds, or mirrors the rank that did) instead of each on its next volume."""
+        eng = self.pipe.unet
+        if eng.note_volume_flag(raised) and self.board is not None:
+            with torch.cuda.stream(cs):
+                self.board.recalibrate(eng, lambda: eng.calibrate_volume(dev, self.pipe.tile_zyx, self.pipe.overlap_zyx, self.pipe.crop_zyx))
 
     def run(self, images: Sequence, rank: int = 0, world: int = 1, queue=None) -> Iterator[Tuple[int, VolumeResult]]:
         """Yield (index, result) for the volumes this worker processes, in its processing order.  ``queue`` (a
@@ -208,6 +219,8 @@ class CohortRunner:
             t0 = clock()
             dev, ev, img = nxt.result()
             t1 = clock()
+            if self.board is not None:
+                self.board.poll(self.pipe.unet)                           # another rank's recalibration, if one was published since the last volume
             with torch.cuda.stream(cs):
                 cs.wait_event(ev)
                 dev.record_stream(cs)                                     # allocated on the copy stream, read by the compute stream

@@ -1407,6 +1407,10 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         // (A/B timing of the bookkeeping), so that the subnormal low-term loss cannot come back silently
         OAI_CHECK_ARG(value == 1 || h->calibrated, "oai_unet_set_option: census 0 needs a calibrated handle (activation exponents set)");
         h->opt_census = value;
+    } else if (!strcmp(name, "calibrated")) {          // only clearing: setting goes through oai_unet_set_act_exponents / a settled oai_unet_calibrate_step
+        OAI_CHECK_ARG(value == 0, "oai_unet_set_option: calibrated can only be cleared (0)");
+        OAI_CHECK_ARG(h->opt_census == 1, "oai_unet_set_option: an uncalibrated handle needs the census (option census is 0)");
+        h->calibrated = false;
     } else if (!strcmp(name, "fuse_first")) {
         OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: fuse_first must be 0 or 1");
         h->fuse_first = value;

@@ -634,8 +634,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 if constexpr (M16) {
                     // ---- 14 steps of tap pairs on v_mfma_f32_16x16x32_f16 (see the kernel's header comment).  Vector-memory order per step:
                     // Y'(j+1) behind pass B | X' lo(j+1) behind pass C lo | X' hi(j+1) behind pass C hi; the counted waits leave exactly the
-                    // younger requests in flight.  (The fragments of this chunk's step 0 were requested during the previous chunk's last step
-                    // -- or in the prologue -- and have landed behind the staging wait above: vmcnt(0) is global.)
+                    // younger requests in flight.  (The fragments of this chunk's step 0 were requested at the chunk's top, above, and have
+                    // landed behind the staging wait: vmcnt(0) is global.  Invariant: every asm load is requested AND waited for inside one basic block.)
                     constexpr int SLB = HY * HX * 64;                           // bytes between the z slices of the halo box
                     constexpr int POFF = (RX >= 32 ? 16 : (16 / RX) * HX) * 64;  // ... between rows 0-15 and rows 16-31 of the wave's tile
                     auto tapc = [](int q) constexpr { return ((q / 3) * HY + q % 3) * HX * 64; };      // tap (dz, dy) = q, dx 0

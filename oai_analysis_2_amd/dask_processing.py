@@ -113,7 +113,7 @@ def process_cohort(images: Sequence, atlas_image, worker: Optional[Worker] = Non
     both probability maps on the atlas grid.  Yields (index, VolumeResult) for the volumes THIS rank processed.
     ``images``: paths or Images (all ranks pass the same list; only claimed entries are read)."""
     from .cohort import CohortRunner
-    from .parallel import VolumeQueue, sync_calibration
+    from .parallel import CalibrationBoard, VolumeQueue, sync_calibration
     from .pipeline import VolumePipeline
     w = worker or get_worker()
     seg = w.segmenter
@@ -135,7 +135,9 @@ def process_cohort(images: Sequence, atlas_image, worker: Optional[Worker] = Non
         sync_calibration(eng, _calibrate_on_first)
     pipe = VolumePipeline(eng, w.registerer.register_module, readimage(atlas_image), tile_zyx=seg.tile_zyx, overlap_zyx=ovl[::-1],
                           crop_zyx=(ovl[2], ovl[0], ovl[1]))
-    runner = CohortRunner(pipe, keep_on_device=keep_on_device)
+    import torch.distributed as dist
+    board = CalibrationBoard() if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    runner = CohortRunner(pipe, keep_on_device=keep_on_device, board=board)
 
     class _Lazy(Sequence):                      # reads + normalises a volume when the runner asks for it (after it was claimed)
         def __len__(self_inner):

@@ -380,20 +380,95 @@ def sync_calibration(engine, calibrate_fn: Callable[[], None], store=None, name:
         return doc["act_exponents"]
     store.wait([name])
     doc = json.loads(store.get(name))
+    try:
+        _mirror_calibration_doc(engine, doc)
+    except RuntimeError as exc:
+        raise RuntimeError(f"sync_calibration: {exc} (rank 0)") from None
+    return doc["act_exponents"]
+
+
+def _mirror_calibration_doc(engine, doc) -> None:
+    """Take over a published calibration outcome (the receiving half of ``sync_calibration``)."""
     if doc.get("status") == "error":
-        raise RuntimeError(f"sync_calibration: the calibration failed on rank 0 ({doc.get('message')})")
+        raise RuntimeError(f"calibration failed on the publishing rank ({doc.get('message')})")
     if doc.get("weights_sha256") != getattr(engine, "weights_sha256", None):
-        raise RuntimeError("sync_calibration: rank 0 holds other weights than this rank")
+        raise RuntimeError("the publishing rank holds other weights than this rank")
     st = doc["status"]
     if st == "calibrated":
         engine.set_act_exponents(doc["act_exponents"])
     elif st == "refused_f32":
         if not hasattr(engine, "refuse_fp16"):
-            raise RuntimeError("sync_calibration: rank 0 refused fp16x3 and this engine cannot mirror it")
-        engine.refuse_fp16("mirrored from rank 0")
+            raise RuntimeError("the publishing rank refused fp16x3 and this engine cannot mirror it")
+        engine.refuse_fp16("mirrored from the publishing rank")
     elif st == "no_census":
         if hasattr(engine, "mark_no_census"):
             engine.mark_no_census()
     else:
-        raise RuntimeError(f"sync_calibration: unknown status {st!r} from rank 0")
-    return doc["act_exponents"]
+        raise RuntimeError(f"unknown calibration status {st!r}")
+
+
+class CalibrationBoard:
+    """ONE recalibration for all ranks of a volume-parallel cohort when a calibration FILE turns out not to fit the data.
+
+    ``UNetEngine.note_volume_flag`` drops a sidecar's calibration after three flagged volumes in a row.  In ``process_cohort`` every rank
+    keeps its own streak and pulls volumes from a shared queue asynchronously: left alone, each rank would recalibrate on whichever volume
+    it sees next, and a volume's last bits would depend on the rank again -- what ``sync_calibration`` exists to prevent.  The ranks share no
+    lockstep point (no collective per volume), so the agreement goes through the process group's key-value store:
+
+    * the first rank whose engine drops the calibration CLAIMS the epoch (``store.add`` on a counter: exactly one caller sees 1),
+      recalibrates on the volume it holds and publishes the outcome (status + exponents, like ``sync_calibration``);
+    * a rank that drops later finds the epoch claimed, waits for the publication and mirrors it instead of calibrating;
+    * every rank ``poll``s (non-blocking ``store.check``) before it queues a volume and mirrors a publication it has not seen yet.
+
+    Volumes already queued under the old exponents finish under them (they are flagged and repeated in exact fp32 if they do not fit --
+    never silently wrong); from the first poll after the publication on, all ranks run the same exponents.  A key is ALWAYS published
+    by the claimant (status "error" when its calibration raised), so a waiting rank cannot hang until the store's timeout."""
+
+    def __init__(self, store=None, name: str = "oai_fp16recal"):
+        if store is None and dist.is_initialized():
+            from torch.distributed import distributed_c10d
+            store = distributed_c10d._get_default_store()
+        self.store, self.name, self.epoch = store, name, 0
+
+    def _key(self, what: str) -> str:
+        return f"{self.name}/{what}{self.epoch + 1}"
+
+    def poll(self, engine) -> bool:
+        """Mirror every publication this rank has not seen yet; never blocks.  True if the engine's calibration changed."""
+        changed = False
+        while self.store is not None and self.store.check([self._key("e")]):
+            import json
+            _mirror_calibration_doc(engine, json.loads(self.store.get(self._key("e"))))
+            self.epoch += 1
+            changed = True
+        return changed
+
+    def recalibrate(self, engine, calibrate_fn: Callable[[], None]) -> bool:
+        """Called by a rank whose engine has just dropped its calibration.  True if THIS rank calibrated (``calibrate_fn()``), False if it
+        mirrored another rank's outcome."""
+        import json
+        if self.store is None:
+            calibrate_fn()
+            return True
+        if self.poll(engine):                       # somebody published since this rank last looked
+            return False
+        if self.store.add(self._key("claim"), 1) != 1:
+            self.store.wait([self._key("e")])
+            self.poll(engine)
+            return False
+        doc = {"weights_sha256": getattr(engine, "weights_sha256", None)}
+        try:
+            calibrate_fn()
+            st = engine.calibration_status() if hasattr(engine, "calibration_status") else ("calibrated" if engine.act_exponents()[1] else "uncalibrated")
+            if st == "uncalibrated":
+                raise RuntimeError("calibrate_fn left the engine uncalibrated")
+            doc.update(status=st, act_exponents=engine.act_exponents()[0], precision=getattr(engine, "effective_precision", None))
+        except Exception as exc:                    # noqa: BLE001 - the waiting ranks must hear about it
+            doc.update(status="error", message=f"{type(exc).__name__}: {exc}")
+            self.store.set(self._key("e"), json.dumps(doc))
+            self.epoch += 1
+            raise
+        self.store.set(self._key("e"), json.dumps(doc))
+        self.epoch += 1
+        return True
+

@@ -83,6 +83,7 @@ class UNetEngine:
                           f"{name}.1.running_mean", f"{name}.1.running_var", f"{name}.1.num_batches_tracked"}
             for t in keep[n_before - 1:]:
                 digest.update(t.numpy().tobytes())
+        self._weights_sha256_r4 = digest.copy().hexdigest() if float(bn_eps) == BN_EPS else None      # what sidecars written before round 5 carry (no bn_eps)
         digest.update(np.float32(bn_eps).tobytes())       # folded into the packed epilogue affine: part of "the network as the kernels see it" 
         self.weights_sha256 = digest.hexdigest()
         extra = set(state_dict) - known
@@ -106,6 +107,8 @@ class UNetEngine:
         self.calibration_source = "none"                # "none" | "file" | "set" | "calibrated"
         self.calibration_census = None                  # per-layer maxima the exponents were chosen from (None when they were set / read from an old file)
         self._flag_streak = 0                           # consecutive volumes that raised the range flag under a calibration read from a file (note_volume_flag)
+        self._dropped_file = None                       # (path, sha256 of its bytes) of a sidecar that note_volume_flag dropped: never read again unless rewritten
+        self.calibration_volume_id: Optional[str] = None
         if precision != "f32":
             self.set_precision(precision)
 
@@ -144,9 +147,10 @@ class UNetEngine:
     def note_volume_flag(self, raised: bool, limit: int = 3) -> bool:
         """Per-volume bookkeeping of the callers that repeat a flagged volume in fp32: ``limit`` CONSECUTIVE flagged volumes under a
         calibration that came from a file mean the file does not describe this data (an unrepresentative first volume pinned its
-        exponents: every later volume would pay the fp32 repeat, silently, forever -- ADVICE r4).  The file is then ignored: the
-        engine recalibrates on the next volume it sees (and rewrites the file only if calibration_write is set).  Returns True when
-        that happened."""
+        exponents: every later volume would pay the fp32 repeat, silently, forever -- ADVICE r4).  The calibration is then DROPPED
+        (``drop_calibration``: the handle itself becomes uncalibrated, the file is remembered and not read again): a single process
+        recalibrates on the next volume it sees, the ranks of a cohort agree on ONE new calibration (parallel.CalibrationBoard).
+        Returns True when that happened."""
         if not raised:
             self._flag_streak = 0
             return False
@@ -154,11 +158,31 @@ class UNetEngine:
         if self._flag_streak >= limit and self.calibration_source == "file" and not self._fp16_refused:
             warnings.warn(f"{self._flag_streak} consecutive volumes left the range window of the fp16x3 calibration read from "
                           f"{self.calibration_file}: ignoring that file and recalibrating on the next volume")
-            self._calibrated = False
-            self.calibration_source = "none"
-            self._flag_streak = 0
+            self.drop_calibration()
             return True
         return False
+
+    @staticmethod
+    def _file_sha256(path: Optional[str]) -> Optional[str]:
+        try:
+            with open(path, "rb") as f:
+                return hashlib.sha256(f.read()).hexdigest()
+        except (OSError, TypeError):
+            return None
+
+    def drop_calibration(self) -> None:
+        """Forget the calibration in the ONE place that holds it -- the library handle (option "calibrated" 0) -- and in this object's
+        mirror of it, so that ``calibration_status()``, ``_needs_calibration()`` and ``parallel.sync_calibration`` agree (only the
+        Python flag used to be cleared: rank 0 then published the dropped file's exponents as "calibrated").  A calibration that came from a
+        file: the file's identity (path + content hash) is remembered and ``set_calibration_file`` does not read it again until it changes."""
+        if self.calibration_source == "file" and self.calibration_file:
+            self._dropped_file = (self.calibration_file, self._file_sha256(self.calibration_file))
+        _lib.check(self.lib.oai_unet_set_option(self._h, b"calibrated", 0), "oai_unet_set_option")
+        self._calibrated = False
+        self.calibration_source = "none"
+        self.calibration_census = None
+        self.calibration_volume_id = None
+        self._flag_streak = 0
 
     def set_precision(self, precision: str) -> None:
         """Arithmetic of the 3x3x3 conv layers: "f32" (exact fp32 MFMA), "fp16x3" (fp32-grade split fp16, the default of the
@@ -262,7 +286,7 @@ class UNetEngine:
         if not cal:
             raise _lib.OaiError("save_calibration: the engine is not calibrated")
         doc = {"format": 1, "precision": "fp16x3", "weights_sha256": self.weights_sha256, "act_exponents": exps, "note": note,
-               "census_max": self.calibration_census, "volume_id": volume_id or getattr(self, "calibration_volume_id", None)}
+               "census_max": self.calibration_census, "volume_id": volume_id or self.calibration_volume_id}
         tmp = f"{path}.tmp.{os.getpid()}"
         with open(tmp, "w") as f:
             json.dump(doc, f)
@@ -283,8 +307,12 @@ class UNetEngine:
             warnings.warn(f"fp16x3 calibration file {path} is unreadable ({exc}): ignoring it")
             return False
         if doc.get("weights_sha256") != self.weights_sha256:
-            warnings.warn(f"fp16x3 calibration file {path} belongs to other weights: ignoring it")
-            return False
+            if self._weights_sha256_r4 is not None and doc.get("weights_sha256") == self._weights_sha256_r4:
+                pass          # a sidecar from before bn_eps was part of the digest, for these weights at the default eps: the same network
+            else:
+                warnings.warn(f"fp16x3 calibration file {path} belongs to other weights (or another bn_eps): ignoring it -- "
+                              f"re-run Segmenter3DInPatchClassWise.calibrate(image) to rewrite it")
+                return False
         try:
             self.set_act_exponents(exps)           # (the library checks the range: an edited file with wild exponents is refused there)
         except _lib.OaiError as exc:
@@ -300,7 +328,11 @@ class UNetEngine:
         ``write=True`` (opt-in): also write it after the next successful calibrate().  None detaches."""
         self.calibration_file = path
         self.calibration_write = bool(path) and bool(write)
-        return bool(path) and not self._calibrated and self.load_calibration(path)
+        if not path or self._calibrated:
+            return False
+        if self._dropped_file is not None and self._dropped_file[0] == path and self._dropped_file[1] == self._file_sha256(path):
+            return False                 # the very file this engine dropped for not fitting the data: not again (a rewritten one is read)
+        return self.load_calibration(path)
 
     def calibrate(self, run_pass, max_passes: int = 24) -> int:
         """Choose the activation exponents from representative input: ``run_pass()`` queues one fp16x3 pass (segment_tiles /

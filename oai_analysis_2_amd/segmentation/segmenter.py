@@ -110,8 +110,8 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
             eng.set_precision(precision)
         if precision == "fp16x3" and (eng.calibration_file != self.calibration_file or eng.calibration_write != self.calibration_write):
             eng.set_calibration_file(self.calibration_file, write=self.calibration_write)
-        if precision == "fp16x3" and self.calibration_write and eng.calibration_status() == "uncalibrated":
-            eng.calibration_volume_id = _volume_id(vol)             # what the sidecar will say it was calibrated on
+        if precision == "fp16x3" and eng.calibration_status() == "uncalibrated":
+            eng.calibration_volume_id = _volume_id(vol) if self.calibration_write else None    # what a sidecar will say it was calibrated on
         blocks = eng.segment_tiles(vol, self.tile_zyx, ovl_zyx, tile_range, 0 if if_output_prob_map else 1, batch,
                                    crop_zyx if min(crop_zyx) > 0 else None)
         # (eng.effective_precision: "f32" when this network's calibration was refused -- then there is no range window to leave)
@@ -142,13 +142,17 @@ class Segmenter3DInPatchClassWise(Segmenter3DInPatch):
         if not self.ready:
             self.pred_setup()
         eng = self.model.engine
+        if eng.fp16_refused:                                         # set_precision("fp16x3") would silently stay "f32" and calibrate_volume raise
+            return {"status": "refused_f32", "passes": -1, "act_exponents": eng.act_exponents()[0], "census_max": None, "volume_id": None, "file": None}
         if eng.precision != "fp16x3":
             eng.set_precision("fp16x3")
         vol = torch.as_tensor(np.ascontiguousarray(as_image(image).array, dtype=np.float32)).to(eng.device)
         ovl_xyz = tuple(int(v) for v in self.config["overlap_size"])
         crop_zyx = (ovl_xyz[2], ovl_xyz[0], ovl_xyz[1])
-        eng.set_calibration_file(self.calibration_file, write=False)
-        eng._calibrated = False                                      # (an explicit request replaces whatever the file held)
+        eng.calibration_file, eng.calibration_write = self.calibration_file, False
+        if eng.calibration_status() == "calibrated":
+            eng.drop_calibration()                                   # (an explicit request replaces whatever the engine held -- in the handle too)
+            eng._dropped_file = None                                 # ... which is no verdict about the file
         eng.calibration_volume_id = _volume_id(vol)
         passes = eng.calibrate_volume(vol, self.tile_zyx, ovl_xyz[::-1], crop_zyx if min(crop_zyx) > 0 else None)
         if write and self.calibration_file and eng.calibration_status() == "calibrated":

@@ -199,3 +199,30 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
                 in_flight = False
             elif in_flight and ("s_cbranch" in ln or "s_branch" in ln or "s_setpc" in ln):
                 raise AssertionError(f"{sym}: a branch while an inline-asm fragment load is in flight: {ln.strip()}")
+    # (h) ADVICE r5 (medium): launch_conv3_shape instantiates the M16 variant for FIVE strip shapes x MREP 2 / 4 as well, all with the same hand-counted
+    # `s_waitcnt vmcnt(N)` over inline-asm fragment loads -- a compiler-made spill, reload or edge copy in any of them shifts the counts silently.  The
+    # guards run over EVERY conv3_igemm_sres<..., M16 = true> symbol of the library (found by its mangled name, not a hard-coded list): no branch while
+    # a fragment load is in flight, no scratch traffic anywhere between two MFMAs of a tap stream, no compiler-made vector-memory load (anything but
+    # the asm forms: SGPR-base global_load_dwordx4 and the LDS-DMA pieces) inside a tap stream, only the 16x16x32 shape.
+    syms = re.findall(r"^[0-9a-f]+ <(_ZN3oai16conv3_igemm_sresI\w*Lb1EEEvNS_8ConvArgsEPKh)>:", text, flags=re.M)
+    assert len(syms) >= 13, f"expected the main, FIRST and 5 x 2 strip instantiations of the M16 direct kernel, found {len(syms)}"
+    for sym in syms:
+        body = [ln.split("//")[0] for ln in re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M).group(1).split("\n")]
+        mf_i = [i for i, ln in enumerate(body) if "v_mfma_f32_16x16x32_f16" in ln]
+        assert len(mf_i) >= 984 and not [ln for ln in body if "v_mfma_f32_32x32x16_f16" in ln], sym
+        assert not [ln for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1] if "scratch_" in ln], f"{sym}: scratch traffic inside a tap stream"
+        loads = [ln for ln in body if "global_load_dwordx4" in ln and "lds" not in ln]
+        assert len(loads) >= 100 and all("s[" in ln for ln in loads), f"{sym}: a fragment load that is not the SGPR-base asm form"
+        in_flight = False
+        for ln in body:
+            if "global_load_dwordx4" in ln and "lds" not in ln:
+                in_flight = True
+            elif "s_waitcnt" in ln and "vmcnt(0)" in ln:
+                in_flight = False
+            elif in_flight and ("s_cbranch" in ln or "s_branch" in ln or "s_setpc" in ln):
+                raise AssertionError(f"{sym}: a branch while an inline-asm fragment load is in flight: {ln.strip()}")
+        # (the counted waits live in the tap streams: there every vector-memory load must be one of the two asm forms.  Outside them -- the scatter
+        #  copy-out of the FIRST instantiation reads tile boxes -- the compiler issues and waits for its own loads)
+        made = [ln.strip() for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1]
+                if re.search(r"\b(scratch_load|buffer_load|global_load_(?!dwordx4|lds_dwordx4))", ln)]
+        assert not made, f"{sym}: compiler-made vector-memory loads inside a counted tap stream: {made[:3]}"

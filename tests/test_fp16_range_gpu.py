@@ -281,11 +281,53 @@ def test_a_calibration_file_that_does_not_fit_the_data_is_dropped_after_three_fl
             w.segment_array(quiet[i], True)
         eng = w.model.engine
         assert eng.calibration_source == ("file" if i < 2 else "none")
+    # ONE piece of state.  The drop reached the library handle too, so the engine's single source of "calibrated?" -- which
+    # parallel.sync_calibration publishes from -- says uncalibrated, and the dropped file is not read again (not by the segmenter's next call,
+    # not by process_cohort's set_calibration_file) until somebody rewrites it
+    assert eng.calibration_status() == "uncalibrated" and eng.act_exponents()[1] is False and eng._needs_calibration()
+    assert eng.set_calibration_file(eng.calibration_file) is False and eng.calibration_status() == "uncalibrated"
+    from oai_analysis_2_amd import parallel
+    calls = []
+    exps_file = eng.act_exponents()[0]
+    assert parallel.sync_calibration(eng, lambda: calls.append(1) or eng.calibrate_volume(
+        torch.from_numpy(quiet[3]).cuda(), w.tile_zyx, (8, 16, 16), (8, 16, 16))) != exps_file and calls == [1]       # (would have returned the file's exponents, uncalibrated-by-flag)
+    assert eng.calibration_status() == "calibrated" and eng.calibration_source == "calibrated"
+    eng.drop_calibration()                                                 # back to the state behind the drop, for the segmenter's own path
     w.segment_array(quiet[3], True)                                        # recalibrates on this volume: no flag, no repeat
     assert eng.calibration_source == "calibrated" and eng._flag_streak == 0 and not eng.range_overflow()
+    assert eng.calibration_volume_id is None                               # (no sidecar will be written: nothing to name)
     ref = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td, precision="f32", fp16_calibration_file=False)).segment_array(quiet[1], True)
     # (200 x the usual input: logits of several hundred, so a 1e-6 relative logit difference is ~1e-4 of probability on the sigmoid's flank)
     assert np.abs(w.segment_array(quiet[1], True) - ref).max() < 1e-3
+
+
+def test_a_sidecar_from_before_bn_eps_was_hashed_is_still_read_and_calibrate_reports_a_refusal(tmp_path):
+    """folding bn_eps into weights_sha256 orphaned every existing sidecar (each process then warned and calibrated on its own
+    first volume -- the dependence the sidecar removes).  A file whose hash is the pre-round-5 digest of THESE weights is accepted at the
+    default eps (and only there); and Segmenter.calibrate() on an engine whose fp16x3 was refused says so instead of raising."""
+    import json
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    from oai_analysis_2_amd.segmentation.segmenter import Segmenter3DInPatchClassWise
+    sd = make_unet_state_dict(seed=5)
+    eng = UNetEngine(sd, precision="fp16x3")
+    path = str(tmp_path / "old.fp16cal.json")
+    exps = [3] * 17 + [0]
+    with open(path, "w") as f:
+        json.dump({"format": 1, "precision": "fp16x3", "weights_sha256": eng._weights_sha256_r4, "act_exponents": exps}, f)
+    assert eng._weights_sha256_r4 != eng.weights_sha256
+    assert eng.load_calibration(path) and eng.act_exponents() == (exps, True) and eng.calibration_source == "file"
+    other_eps = UNetEngine(sd, precision="fp16x3", bn_eps=1e-3)
+    assert other_eps._weights_sha256_r4 is None
+    with pytest.warns(UserWarning, match="other weights"):
+        assert not other_eps.load_calibration(path)
+    td = str(tmp_path)
+    _write_models(td, 5)
+    w = Segmenter3DInPatchClassWise(mode="pred", config=_seg_config(td))
+    w.pred_setup()
+    with pytest.warns(UserWarning):
+        w.model.engine.refuse_fp16("test")
+    got = w.calibrate(make_volume(1, (40, 200, 200)))
+    assert got["status"] == "refused_f32" and got["file"] is None
 
 
 def test_a_network_that_cannot_be_calibrated_runs_f32_with_a_warning():

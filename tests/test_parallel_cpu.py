@@ -356,3 +356,74 @@ def test_sync_calibration_propagates_rank0s_outcome(tmp_path, scenario):
         else:
             assert err and ("rank 0" in err or r == 0), err
             assert ("unreadable" in err) if scenario == "error" else ("uncalibrated" in err)
+
+
+# ---- a dropped calibration FILE: the ranks of a volume-parallel cohort agree on ONE recalibration -----------------
+
+def test_calibration_board_one_rank_recalibrates_and_every_rank_mirrors_it():
+    """Three "ranks" (threads over one HashStore -- the board only touches the store) whose engines run a file calibration.  Rank 1 hits the
+    drop first: it claims the epoch, calibrates on ITS volume and publishes; rank 2 drops later, finds the epoch claimed and mirrors instead
+    of calibrating; rank 0 never drops and picks the publication up at its next poll.  Everybody ends on rank 1's exponents, exactly one
+    calibration ran; a board without a store (single process) just calibrates."""
+    import threading
+    store = dist.HashStore()
+    engines = [_FakeEngine() for _ in range(3)]
+    for e in engines:
+        e.set_act_exponents([1] * 17 + [0])                     # "from the sidecar"
+    boards = [parallel.CalibrationBoard(store, name="t") for _ in range(3)]
+    assert not boards[0].poll(engines[0])                       # nothing published yet: non-blocking, nothing changes
+    ran = []
+
+    def cal(rank):
+        def fn():
+            ran.append(rank)
+            engines[rank].set_act_exponents([rank + 4] * 17 + [0])
+        return fn
+
+    gate = threading.Event()
+    out = {}
+
+    def late_rank():                                            # rank 2 drops while rank 1 is still calibrating: it must WAIT, then mirror
+        gate.wait()
+        out[2] = boards[2].recalibrate(engines[2], cal(2))
+
+    th = threading.Thread(target=late_rank)
+    th.start()
+
+    def slow_cal():
+        gate.set()                                              # rank 2 arrives while the epoch is claimed but not published
+        import time
+        time.sleep(0.2)
+        cal(1)()
+
+    out[1] = boards[1].recalibrate(engines[1], slow_cal)
+    th.join(timeout=30)
+    assert not th.is_alive()
+    assert out == {1: True, 2: False} and ran == [1]
+    assert boards[0].poll(engines[0]) and not boards[0].poll(engines[0])
+    for e in engines:
+        assert e.act_exponents() == ([5] * 17 + [0], True)
+    assert [b.epoch for b in boards] == [1, 1, 1]
+    # a rank that drops after it has (unknowingly) been superseded mirrors at once
+    solo = parallel.CalibrationBoard(None)
+    e = _FakeEngine()
+    assert solo.recalibrate(e, lambda: e.set_act_exponents([2] * 17 + [0])) and e.act_exponents()[0][0] == 2
+
+
+def test_calibration_board_publishes_a_failure_instead_of_leaving_ranks_waiting():
+    store = dist.HashStore()
+    a, b = parallel.CalibrationBoard(store, name="f"), parallel.CalibrationBoard(store, name="f")
+    ea, eb = _FakeEngine(), _FakeEngine()
+
+    def boom():
+        raise OSError("volume unreadable")
+
+    with pytest.raises(OSError):
+        a.recalibrate(ea, boom)
+    with pytest.raises(RuntimeError, match="unreadable"):
+        b.recalibrate(eb, lambda: eb.set_act_exponents([3] * 18))     # the epoch is claimed and published as an error: no hang, no own calibration
+    assert eb.act_exponents()[1] is False
+    c, ec = parallel.CalibrationBoard(store, name="g"), _FakeEngine()
+    with pytest.raises(RuntimeError, match="uncalibrated"):
+        c.recalibrate(ec, lambda: None)                                # returned without a verdict: published as an error too
+

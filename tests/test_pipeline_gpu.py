@@ -43,6 +43,37 @@ def test_fused_two_map_resample_is_bit_identical_to_the_separate_path():
         pipe.resample(maps, res.phi, meta, (5, nz + 1))
 
 
+def test_stitch_reads_a_ragged_gather_buffer_in_place_on_the_device():
+    """ADVICE r5 (low): ``oai_stitch_blocks_ranged`` over a slot table with n_ranges > 1 had only run at world 1 (one range, nothing padded);
+    the ragged, in-place layout an 8-rank all_gather leaves was checked over gloo on CPU tensors with a Python re-implementation of the slot
+    lookup.  Here ONE GPU builds that layout from a real ``segment_tiles`` result -- ragged bounds, stride = the longest range, every slot's
+    tail filled with NaN garbage, the ranges written straight into their slots (``segment_tiles(out=slot)``) -- and the stitch of the
+    ``GatheredBlocks`` must equal the stitch of the compact tensor bit for bit."""
+    from oai_analysis_2_amd import parallel
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine, tile_grid
+    eng = UNetEngine(make_unet_state_dict(1, width_div=2), precision="fp16x3")
+    shape, tile, ovl = (40, 100, 90), (16, 32, 32), (4, 8, 8)
+    vol = torch.from_numpy(make_volume(3, shape)).cuda()
+    eff, grid, n = tile_grid(shape, tile, ovl)
+    compact = eng.segment_tiles(vol, tile, ovl, crop_zyx=ovl)
+    want = eng.stitch(compact, shape, tile, ovl, ovl)
+    assert n == 210
+    # 8 ragged ranges (27 / 26 / ... like a cost-balanced split), one-tile ranges at both ends, an EMPTY range in the middle
+    for bounds in ([0, 27, 53, 80, 106, 132, 158, 184, 210], [0, 1, 209, 210], [0, 105, 105, 210]):
+        world = len(bounds) - 1
+        stride = max(bounds[r + 1] - bounds[r] for r in range(world))
+        buf = torch.full((world * stride, eng.n_classes, *eff), float("nan"), dtype=torch.float32, device=vol.device)
+        g = parallel.GatheredBlocks(buf, bounds, stride)
+        for r in range(world):
+            if bounds[r + 1] > bounds[r]:
+                got = eng.segment_tiles(vol, tile, ovl, (bounds[r], bounds[r + 1]), crop_zyx=ovl, out=g.slot(r))    # computed straight into the slot
+                assert got.data_ptr() == g.slot(r).data_ptr()
+        assert torch.equal(g.compact(), compact)
+        assert torch.equal(eng.stitch(g, shape, tile, ovl, ovl), want), bounds
+        assert torch.isnan(buf).sum().item() == (world * stride - n) * eng.n_classes * eff[0] * eff[1] * eff[2]     # the tails were never written
+    assert not torch.isnan(want).any()
+
+
 def test_pipeline_and_cohort_repeat_an_overflowing_volume_in_fp32():
     """Weights that push ec0 beyond 65504: fp16x3 must never return garbage -- run() repeats in fp32, run(check=False) hands
     the flag back, CohortRunner repeats at download time; results equal the fp32 engine's."""
