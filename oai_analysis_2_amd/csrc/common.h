@@ -29,10 +29,10 @@ int set_error(int code, const char* fmt, ...);
 
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
-// Diagnostic switches (timing ablations that produce WRONG results, kernel-variant selection by environment) exist only in
-// builds compiled with -DOAI_DIAG (scripts/build_diag.sh -> a separate .so loaded through OAI_LIB_PATH).  The production
-// library never reads the environment: diag_env() is the constant default and every `OAI_DBG_BIT(...)` branch (unet_kernels.h)
-// folds away.
+// Diagnostics (in-kernel phase stamps, kernel-variant selection by environment -- nothing that changes a result) exist only in
+// builds compiled with -DOAI_DIAG (a separate .so that scripts/ load through OAI_LIB_PATH).  The production library never reads
+// the environment: diag_env() is the constant default.  The timing ablations with wrong results that rounds 2-5 kept behind
+// OAI_DBG / OAI_ABLATE / OAI_EXP switches are written up (profiles/r0*_*.md) and were removed from the sources in round 6.
 #ifdef OAI_DIAG
 int diag_env(const char* name, int dflt);
 #else

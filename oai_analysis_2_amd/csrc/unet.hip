@@ -699,7 +699,6 @@ static int fill_conv_args(const oai_unet* h, const Layer& L, const float* s0, co
     a.boxes = boxes;
     a.pool_out = pool_out;
     a.range_flag = h->range_flag;
-    { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }      // -DOAI_DIAG builds only; constant 0 otherwise
 #ifdef OAI_DIAG
     a.stamps = diag_stamps();
     { static const int only = diag_env("OAI_STAMP_LAYER", -1); if (only >= 0 && &L != &h->L[only]) a.stamps = nullptr; }   // one layer's budget (EC1 = 1 ...)
@@ -807,15 +806,6 @@ static int launch_wino_shape(const oai_unet* h, const Layer& L, ConvArgs a, cons
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-#if (OAI_EXP & 64)
-    if (TY == 8 && L.panel_wino16) {                                   // timing only (unet_wino.h): the main shape as two independent four-wave workgroups per CU, 64 couts each
-        a.wpanel = L.panel_wino16;
-        a.ncb = a.Cout / 64;
-        unsigned g2 = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
-        if (h->xcd_group > 0) { a.nblocks = (int)g2; const unsigned q = 8u * (unsigned)h->xcd_group; g2 = (g2 + q - 1) / q * q; }
-        conv3_wino_sres<1, 8, 4, 1, false, true><<<g2, 256, 0, st>>>(a, h->zero_rec);
-    } else
-#endif
     if (ng == 2 && (h->opt_wino & 16) && L.panel_wino16) {              // the taps on v_mfma_f32_16x16x32_f16 (higher clock at the power wall)
         a.wpanel = L.panel_wino16;
         conv3_wino_sres<2, TY, NP, 1, false, true><<<grid, 512, 0, st>>>(a, h->zero_rec);
@@ -921,7 +911,6 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.boxes = in_boxes;
     a.range_flag = h->range_flag;
     a.zero = h->zero_rec;
-    { static const int dbg = diag_env("OAI_DBG", 0); a.dbg = dbg; }
 #ifdef OAI_DIAG
     a.stamps = diag_stamps();
     { static const int only = diag_env("OAI_STAMP_LAYER", -1); if (only >= 0 && &L != &h->L[only]) a.stamps = nullptr; }   // DC9 = 8, DC6 = 11, DC3 = 14

@@ -10,19 +10,6 @@
 
 namespace oai {
 
-// Diagnostic builds only (never shipped: results are wrong): -DOAI_ABLATE=<bits> removes one ingredient of the conv
-// kernels so that its share of the time can be read off (cdna_hip_programming.md 5.4: ablate before optimising).
-//   1 = no halo staging (global loads + LDS writes), 2 = no weight loads, 4 = no LDS fragment reads
-// Runtime timing switches (ConvArgs::dbg / UpArgs::dbg, results wrong when set) likewise exist only under -DOAI_DIAG.
-#ifdef OAI_DIAG
-#define OAI_DBG_BIT(args, bit) (((args).dbg & (bit)) != 0)
-#else
-#define OAI_DBG_BIT(args, bit) false
-#endif
-#ifndef OAI_ABLATE
-#define OAI_ABLATE 0
-#endif
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
@@ -94,7 +81,7 @@ struct ConvArgs {
     unsigned* census = nullptr;              // split-resident kernels: 16 words of this layer's max |stored activation| (float bits, atomicMax;
                                              // see census_note).  Feeds the per-layer activation exponents and the low-range flag
     unsigned* first_census = nullptr;        // ... of the fused ec0 (instantiation FIRST)
-    int dbg = 0;                             // diagnostic timing switches (OAI_DBG, results wrong when non-zero); 0 in production
+    int reserved0 = 0;                       // (keeps the kernel-argument layout of earlier rounds: the slot of the removed diagnostic switch word)
     unsigned long long* stamps = nullptr;    // -DOAI_DIAG builds: device array of phase cycle sums (oai_diag_stamps); never set in production
     int nblocks = 0, xcd_group = 0;          // split-resident kernel: true workgroup count and the XCD dealing granularity (see xcd_block_id)
     int* ps_plan = nullptr;                  // conv3_wino_sres<..., PS>: the launch's block plan (wino_plan_kernel): counters, block count, per-tile prefix and sub-boxes
@@ -257,9 +244,9 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                     // every wave is done reading the previous chunk
-        if (!(OAI_ABLATE & 1)) halo_store();
+        halo_store();
         __syncthreads();
-        if (!(OAI_ABLATE & 1) && ch + 1 < nchunks) halo_load(ch + 1);   // in flight behind this chunk's 27*KG*MREP*8 MFMAs
+        if (ch + 1 < nchunks) halo_load(ch + 1);   // in flight behind this chunk's 27*KG*MREP*8 MFMAs
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             const int t = st / KG, kg = st % KG;
@@ -269,10 +256,10 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_f32(const ConvArgs a) {
             float4 acur[MREP];
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
-                acur[m] = (OAI_ABLATE & 4) ? bcur[0] : *reinterpret_cast<const float4*>(
+                acur[m] = *reinterpret_cast<const float4*>(
                     a_ptr + (((m + dz) * kConvHY + dy) * kConvHX + dx) * STRIDE + 8 * kg);
 #pragma unroll
-            for (int n = 0; n < NREP; ++n) bnext[n] = (OAI_ABLATE & 2) ? bcur[n] : wp[n * 64];
+            for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
             wp += NREP * 64;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -478,9 +465,9 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
-        if (!(OAI_ABLATE & 1)) halo_store();
+        halo_store();
         __syncthreads();
-        if (!(OAI_ABLATE & 1) && ch + 1 < nchunks) halo_load(ch + 1);
+        if (ch + 1 < nchunks) halo_load(ch + 1);
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
             const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
@@ -489,11 +476,11 @@ __global__ void __launch_bounds__(256, 2) conv3_igemm_bf16s(const ConvArgs a) {
             for (int k = 0; k < NS; ++k)
 #pragma unroll
                 for (int m = 0; m < MREP; ++m)
-                    acur[k][m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(a_ptr + (((m + dz) * HY + dy) * HX + dx) * REC + k * 32);
+                    acur[k][m] = *reinterpret_cast<const float4*>(a_ptr + (((m + dz) * HY + dy) * HX + dx) * REC + k * 32);
 #pragma unroll
             for (int k = 0; k < NS; ++k)
 #pragma unroll
-                for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
+                for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
             wp += STEP;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -572,7 +559,7 @@ struct UpArgs {
     unsigned* census = nullptr;         // split-resident kernel: this layer's 16 census words (see ConvArgs::census)
     const unsigned char* zero = nullptr; // split-resident kernel: 64 zero bytes, the LDS-DMA source of rows / columns that do not exist
     unsigned long long* stamps = nullptr;   // -DOAI_DIAG builds: phase cycle sums of the up-conv kernel at stamps[16..31]
-    int dbg = 0;                        // diagnostic timing switches (OAI_DBG bits 64/128/256/512; results wrong when set)
+    int reserved0 = 0;                  // (keeps the kernel-argument layout of earlier rounds)
     int nblocks = 0, xcd_group = 0;     // split-resident kernel: true workgroup count and the XCD dealing granularity (xcd_block_id): the column
                                         // blocks of one row block read the same A rows and should meet in one L2
 };

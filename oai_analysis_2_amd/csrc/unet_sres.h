@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         __syncthreads();                                 // ... for everybody; and the slots refilled below are read out
                     }
-                    if (ch + 1 < nchunks && !OAI_DBG_BIT(a, 1)) {
+                    if (ch + 1 < nchunks) {
                         if (dz == 0) { issue_plane(ch + 1, 0); issue_plane(ch + 1, 1); }
                         else issue_plane(ch + 1, dz + 1);
                     }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
-                if (!OAI_DBG_BIT(a, 2)) wp += STEP;
+                wp += STEP;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                 const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
 #pragma unroll
                 for (int m = 0; m < ML; ++m)
-                    dst[m] = (OAI_ABLATE & 4) ? bcur[k][0] : *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
+                    dst[m] = *reinterpret_cast<const float4*>(abase + (((m + dz) * HY + dy) * HX + dx) * 64 + sl[dx][k]);
             };
             for (int ch = 0; ch < nchunks; ++ch) {
                 OAI_STAMP(0);
@@ -623,8 +623,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                     // load of this kernel is now requested AND waited for inside one basic block.
                     if constexpr (!FIRST) { m16_req_y(); m16_req_lo(); m16_req_hi(); }
                 }
-                if constexpr (FIRST) { if (!OAI_DBG_BIT(a, 4)) stage_first(ch); }
-                else if (!OAI_DBG_BIT(a, 1) || ch == 0) stage(ch);
+                if constexpr (FIRST) stage_first(ch);
+                else stage(ch);
                 if constexpr (M16 && FIRST) { m16_req_y(); m16_req_lo(); m16_req_hi(); }      // (behind ec0's arithmetic, which has branches: same basic block as the wait below)
                 OAI_STAMP(2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's DMA pieces have landed ...
@@ -768,8 +768,8 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
 #pragma unroll
-                            for (int n = 0; n < NREP; ++n) bnext[k][n] = (OAI_ABLATE & 2) ? bcur[k][n] : wp[(k * NREP + n) * 64];
-                        if (!OAI_DBG_BIT(a, 2)) wp += STEP;
+                            for (int n = 0; n < NREP; ++n) bnext[k][n] = wp[(k * NREP + n) * 64];
+                        wp += STEP;
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
                     }
                 }
             }
-        } else if (!OAI_DBG_BIT(a, 16)) {
+        } else {
             // Piece sidx = it*256 + tid of the image = 16 bytes (q & 3) of the record (chunk q >> 2) of block voxel w = it*32 + (tid >> 3).
             // kTX * kTY = 128, so z = it >> 2 and the (y, x) of w split into a per-LANE part (from tid >> 3 < 32) and a per-ITERATION part (from
             // (it & 3) * 32): the destination is one per-lane 32-bit offset (computed once) + a wave-uniform offset per iteration from a
@@ -1007,7 +1007,7 @@ __global__ void __launch_bounds__(256, (MREP == 2 && !RING) ? 3 : 2) conv3_igemm
         }
         OAI_STAMPB(head ? 4 : 3);
         if constexpr (RX == 16 && RY == 2 && WY == 4 && WX == 1) {
-            if (a.pool_out && !OAI_DBG_BIT(a, 32)) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
+            if (a.pool_out) {            // MaxPool3d(2) fused (see pooled_store in unet_kernels.h), result also in format S
                 unsigned char* pb = reinterpret_cast<unsigned char*>(a.pool_out);
                 const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
                 const bool relu = a.relu != 0;
@@ -1186,8 +1186,8 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                      // ... for everybody (a bare barrier: __syncthreads() would drain vmcnt)
         asm volatile("" ::: "memory");
-        if (ks + 2 < nks && !OAI_DBG_BIT(a, 256)) issue((ks + 2) % 3, ks + 2);
-        if (active && !OAI_DBG_BIT(a, 128)) {
+        if (ks + 2 < nks) issue((ks + 2) % 3, ks + 2);
+        if (active) {
             const unsigned char* sp = ulds + (ks % 3) * kStage;
             float4 at[2][2], bf[2][4];
 #pragma unroll
@@ -1237,7 +1237,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         for (int m = 0; m < 2; ++m) {
             __syncthreads();                                                 // voxel table written / previous half copied out
             OAI_USTAMP(2);
-            if (active && !OAI_DBG_BIT(a, 512)) {
+            if (active) {
                 unsigned vmask = 0;                                          // which of this lane's 16 voxel rows are real outputs
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -1282,7 +1282,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             for (int it = 0; it < 16; ++it) {
                 const int vl = it * 4 + (tid >> 6);                          // image row: block voxel (vl >> 5) * 64 + m * 32 + (vl & 31)
                 const unsigned e = vtab[(vl >> 5) * 64 + m * 32 + (vl & 31)];
-                if (qok && e != ~0u && !OAI_DBG_BIT(a, 64))
+                if (qok && e != ~0u)
                     *reinterpret_cast<float4*>(outb + (size_t)(e + poff) * 64 + inrow) = *reinterpret_cast<const float4*>(ulds + vl * 1024 + q * 16);
             }
             OAI_USTAMP(4);

@@ -37,14 +37,6 @@
 // -- not on the block grid, the batch or the launch box: results do not depend on how tiles are batched.
 #pragma once
 #include "unet_sres2.h"
-// Experimental builds only (build_library(extra_flags=["-DOAI_EXP=<bits>"]) into build/exp/: timing of the epilogue's parts, results wrong):
-// 1 no copy-out stores, 2 no fused pool, 4 no output transform / image (stores of stale LDS) -- CAUTION: bits 1 and 4 leave the activations of later layers
-// zero / stale, and an MFMA loop on such data clocks higher: they price nothing downstream; 16 every copy-out store issued TWICE (same data, same address:
-// the marginal cost of the stores with all data real), 32 plain instead of non-temporal stores.  Never defined in the shipped library.
-#ifndef OAI_EXP
-#define OAI_EXP 0
-#endif
-
 namespace oai {
 
 // Block shapes: TY rows x NP pairs with TY * NP = 32 -- 8 x 4 (the main shape, figures above), 4 x 8 (y remainders of <= 4 rows) and
@@ -75,9 +67,7 @@ namespace oai {
 // multipliers go from a block's epilogue straight into the next block's taps -- no prologue (request, L2 / HBM round trip, transform: ~5 us of a ~70-us
 // block) and no workgroup launch in between (~4 us of an idle CU per block: profiles/r04_wino_stream.md section 6).  Same arithmetic, same order: bit-identical.
 template <int NG, int TY, int NP, int MS = 1, bool WS = false, bool M16 = false, bool PS = false>
-// (-DOAI_EXP bit 64, timing only, results WRONG: the four-wave form <1, TY, NP, 1> as TWO independent workgroups per CU -- its raw box aliased onto half the bytes so that
-//  a workgroup fits 80 KB of LDS; same DMA instructions, same traffic, same transform and tap work: does a second, unsynchronised workgroup fill what one leaves empty?)
-__global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && NG * MS == 1 && !WS) ? 2 : 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
+__global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, 1) conv3_wino_sres(const ConvArgs a, const unsigned char* __restrict__ zero_rec) {
     static_assert(!PS || (WS && !M16), "persistent workgroups: the specialised form");
     constexpr int NT = 256 * NG * MS, MREP = 4 / MS, NREP = 2;
     static_assert((MS == 1 || MS == 2) && NG * MS <= 2, "eight waves at most");
@@ -89,9 +79,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
     constexpr int NIT = (PIECES + NT - 1) / NT;                   // LDS-DMA instructions per thread per chunk: 5 (NG 2) / 10 (NG 1) for 8 x 4
     constexpr int TB = HZ * 4 * HY * NP * 64;                     // 61 440 bytes of T for 8 x 4
     constexpr int RPW = HZ * HY / 4, WNIT = (RPW * RS + 63) / 64;    // WS: halo rows and LDS-DMA instructions per staging wave and chunk (15, 10)
-    constexpr bool kHalfRaw = (OAI_EXP & 64) && NG * MS == 1 && !WS;
-    constexpr int RAWB = WS ? 4 * WNIT * 1024 : kHalfRaw ? NIT * NT * 16 / 2 : NIT * NT * 16;    // 40 960 bytes of raw box (whole 1-KiB wave writes)
-    auto rawo = [](int o) constexpr { return kHalfRaw ? o % RAWB : o; };       // (OAI_EXP 64: byte offsets inside the raw box wrap)
+    constexpr int RAWB = WS ? 4 * WNIT * 1024 : NIT * NT * 16;    // 40 960 bytes of raw box (whole 1-KiB wave writes)
     constexpr int UNITS = HZ * 2 * HY * NP;                       // 480 transform units (hz, half, hy, pair)
     constexpr int XB = 3 * 4 * 4 * 1024;                          // exchange buffer of one cout group: [f][3 slices][4 row groups][lane] x 16 B
     static_assert(NG == 1 || NG == 2, "one or two cout groups");
@@ -199,8 +187,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
         const bool real = ch < nchunks;
         const bool first = ch < nch0;
         const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? ch : ch - nch0) * plane * 64;     // wave-uniform chunk plane
-        const unsigned char* g = (real && poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + poff[it] : zero_rec;
-        lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + rawo((it * NT + wave * 64) * 16)));
+        const unsigned char* g = (real && poff[it] != kNoPiece) ? cbase + poff[it] : zero_rec;
+        lds_dma16(g, __builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16));
     };
     // M16: the piece from a wave-uniform base (SGPR pair) + a 32-bit per-lane offset -- no 64-bit per-lane address, no select against the zero
     // record (hoisted out of the chunk loop those are ten more registers; spilled, their reload inside the taps drains vmcnt).  A piece outside
@@ -210,10 +198,10 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
         const int che = ch < nchunks ? ch : nchunks - 1;
         const bool first = che < nch0;
         const unsigned char* cbase = (first ? s0 : s1) + (size_t)(first ? che : che - nch0) * plane * 64;     // wave-uniform chunk plane
-        const unsigned off = poff[it] != kNoPiece && !OAI_DBG_BIT(a, 131072) ? poff[it] : 0u;
+        const unsigned off = poff[it] != kNoPiece ? poff[it] : 0u;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(cbase), "s"(__builtin_amdgcn_readfirstlane(raw0 + rawo((it * NT + wave * 64) * 16))) : "memory");
+                     : "=&s"(keep) : "v"(off), "s"(cbase), "s"(__builtin_amdgcn_readfirstlane(raw0 + (it * NT + wave * 64) * 16)) : "memory");
     };
     unsigned miss = 0;                                              // bit it: piece it of this thread lies outside the tile
     if constexpr (M16 && !WS) {
@@ -224,7 +212,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
         if (__builtin_amdgcn_ballot_w64(miss != 0) == 0) return;     // (interior blocks: no wave has one)
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-            if (miss & (1u << it)) *reinterpret_cast<float4*>(raw + rawo((it * NT + tid) * 16)) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (miss & (1u << it)) *reinterpret_cast<float4*>(raw + (it * NT + tid) * 16) = float4{0.0f, 0.0f, 0.0f, 0.0f};
     };
     // pieces requested in tap t (for the NEXT chunk): spread over the nine taps, the early taps take the remainder
     auto pieces_in_tap = [](int t) constexpr { return WS ? 0 : NIT / 9 + (t < NIT % 9 ? 1 : 0); };
@@ -278,7 +266,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                 int t = u / NP;
                 const int hy = t % HY; t /= HY;
                 const int hf = t & 1, hz = t >> 1;
-                transform_unit(raw + (kHalfRaw ? ((((hz * HY + hy) * RS) + 4 * p + hf) * 16) % (RAWB - 1024) : (((hz * HY + hy) * RS) + 4 * p + hf) * 16), hz, hy, p, hf, Tl);      // (OAI_EXP 64: the unit's 4 x 2 pieces stay inside the box)
+                transform_unit(raw + (((hz * HY + hy) * RS) + 4 * p + hf) * 16, hz, hy, p, hf, Tl);
             }
         }
     };
@@ -332,7 +320,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
         const unsigned dst = lds_addr_of(raw_w);
 #pragma unroll
         for (int it = 0; it < (WS ? WNIT : 0); ++it) {
-            const unsigned char* g = (wo[WS ? it : 0] != kNoPiece && !OAI_DBG_BIT(a, 131072)) ? cbase + wo[WS ? it : 0] : zero_rec;
+            const unsigned char* g = (wo[WS ? it : 0] != kNoPiece) ? cbase + wo[WS ? it : 0] : zero_rec;
             if (!PS || it + 1 < WNIT || lane < kLastLanes) lds_dma16(g, __builtin_amdgcn_readfirstlane(dst + it * 1024));
         }
     };
@@ -404,11 +392,11 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
 
     f32x4 fs[WS && M16 ? 2 : 1][8];                                  // [set][X' n2 0..3 | Y' n2 0..3]
     auto ws16_request = [&](f32x4 (&d)[8]) __attribute__((always_inline)) {
-        if (!OAI_DBG_BIT(a, 4096)) {
+        {
             d[0] = gload16_asm<0>(wp, wlane); d[1] = gload16_asm<1024>(wp, wlane); d[2] = gload16_asm<2048>(wp, wlane); d[3] = gload16_asm<3072>(wp, wlane);
             d[4] = gload16_asm<0>(wp + 4096, wlane); d[5] = gload16_asm<1024>(wp + 4096, wlane); d[6] = gload16_asm<2048>(wp + 4096, wlane); d[7] = gload16_asm<3072>(wp + 4096, wlane);
         }
-        if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+        wp += STEP * 16;
     };
     auto ws16_landed = [&](f32x4 (&d)[8]) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) :: "memory");
@@ -537,24 +525,20 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
             return;
         }
         for (int ch = 0; ch < nchunks; ++ch) {
-            // (-DOAI_DIAG builds, OAI_DBG bits -- timing only, results wrong: 4096 no weight-fragment loads in the taps, 8192 A fragments of tap 0 for
-            // every tap, 16384 transform of chunk 0 only, 32768 no DMA pieces in the taps, 65536 every weight-fragment load from ONE address
-            // (same instructions, L1-resident: prices the L2 -> L1 leg alone), 131072 every halo piece from the zero record (same DMA
-            // instructions, no HBM / L2 traffic behind them); scripts/wino_var.sh, profiles/r03_winograd.md, r04_wino_stream.md)
             if constexpr (!WS) {
                 if constexpr (M16) {
                     // (round 5) The weight fragments of this chunk's step 0, requested HERE -- they land under the transform (~1 us) -- instead of
                     // during the previous chunk's last step, where hi(0) was requested 16 MFMAs before the chunk-end wait: every chunk ended with
                     // an exposed L2 round trip, for all eight waves (the barrier waits for the slowest).  Same basic block as their first use.
-                    if (!OAI_DBG_BIT(a, 4096)) {
+                    {
 #pragma unroll
                         for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
                         bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane);
                         bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane);
                     }
-                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+                    wp += STEP * 16;
                 }
-                if (!OAI_DBG_BIT(a, 16384) || ch == 0) transform();
+                transform();
                 if constexpr (M16) compute_a16((unsigned)(zp * MREP) * (unsigned)(4 * HY * NP * 64));      // (MS = 2: this wave's slice pair)   behind the transform's register peak, in front of the barrier: under the wait for the slowest wave
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                        // T is complete; the raw box is free for the next chunk's pieces
@@ -575,10 +559,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                 auto lda = [&](unsigned off, int m, int p) __attribute__((always_inline)) {
                     return *reinterpret_cast<const float4*>(Tl + off + m * SL + p * 1024);
                 };
-                bool exp_skip = false;                                  // (-DOAI_EXP bit 128, timing only: step 2 of every chunk without its 96 MFMAs -- every weight-fragment load, halo piece and wait kept:
-                //                                                         what does a pass cost per MFMA at the power wall?  profiles/r05_persistent.md section 6)
                 auto mma = [&](const float4& av, const f32x4& bv, f32x4& c) __attribute__((always_inline)) {
-                    if ((OAI_EXP & 128) && exp_skip) return;
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
                 };
                 // pieces of the NEXT chunk's raw box: requested at the ends of steps 0..3 (step 4 requests nothing: what the chunk-end wait covers was
@@ -593,7 +574,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                         // vector-memory operations younger than Y'(j) at the top of step j: lo(j), hi(j) and the pieces requested at the end of step j - 1
-                    exp_skip = j == 2;
                     const int npp = j > 0 ? np_of(j - 1) : 0;           // (step 0: the fragments were requested at the chunk's top, nothing behind them)
                     if (npp == 0) vm_wait<4>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 1) vm_wait<5>(bY[0], bY[1], bY[2], bY[3]); else if (npp == 2) vm_wait<6>(bY[0], bY[1], bY[2], bY[3]); else vm_wait<7>(bY[0], bY[1], bY[2], bY[3]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -605,7 +585,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
 #pragma unroll
                             for (int n = 0; n < 4; ++n) mma(af[m][p], bY[n], acc4[m][n >> 1][p * 2 + (n & 1)]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j < 4 && !OAI_DBG_BIT(a, 4096)) {               // Y' of the next step
+                    if (j < 4) {               // Y' of the next step
 #pragma unroll
                         for (int n = 0; n < 4; ++n) bY[n] = n == 0 ? gload16_asm<0>(wp + 4096, wlane) : n == 1 ? gload16_asm<1024>(wp + 4096, wlane) : n == 2 ? gload16_asm<2048>(wp + 4096, wlane) : gload16_asm<3072>(wp + 4096, wlane);
                     }
@@ -666,7 +646,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
 #pragma unroll
                                 for (int n = 0; n < 2; ++n) mma(af[m][p], bXlo[n], acc4[m][0][p * 2 + n]);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!OAI_DBG_BIT(a, 4096)) {                    // the low couts of the next step's X'
+                        {                    // the low couts of the next step's X'
                             bXlo[0] = gload16_asm<0>(wp, wlane); bXlo[1] = gload16_asm<1024>(wp, wlane);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -682,11 +662,11 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                             for (int p = 0; p < 2; ++p) af[m][p] = lda(a16[j < 3 ? (j + 1) * 2 : 8], m, p);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (!OAI_DBG_BIT(a, 4096)) {                    // the high couts of the next step's X'
+                        {                    // the high couts of the next step's X'
                             bXhi[0] = gload16_asm<2048>(wp, wlane); bXhi[1] = gload16_asm<3072>(wp, wlane);
                         }
-                        if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
-                        if (!OAI_DBG_BIT(a, 32768)) {
+                        wp += STEP * 16;
+                        {
 #pragma unroll
                             for (int q = 0; q < NIT; ++q)
                                 if (q % 4 == j) issue_piece_s(q, ch + 1);
@@ -720,7 +700,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                     f32x4 (&bc)[2][NREP] = bq[t % 3];
                     f32x4 (&bn)[2][NREP] = bq[(t + 2) % 3];
                     vm_wait<4>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);      // in flight behind B(t): the fragments of tap t+1
-                    if (!OAI_DBG_BIT(a, 4096)) {
+                    {
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -728,7 +708,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                                 bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
                                                   : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
                     }
-                    if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
+                    wp += STEP * 16;
 #pragma unroll
                     for (int m = 0; m < ML; ++m) {
                                 const int step = t * ML + m;                     // aa[step & 1] holds (t, m)
@@ -737,7 +717,6 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                         else if (t + 1 < 9) load_pair(aa[(step + 1) & 1], t + 1, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         float4 (&ac)[2] = aa[step & 1];
-                        if (OAI_DBG_BIT(a, 262144)) { asm volatile("" :: "v"(ac[0].x), "v"(ac[0].w), "v"(ac[1].x), "v"(ac[1].w)); continue; }      // (timing only: the taps without their MFMAs)
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(ac[0], __builtin_bit_cast(float4, bc[0][n]), acc[m][n]);      // a0.b0
 #pragma unroll
@@ -775,8 +754,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                     else if (younger == 1) vm_wait<1>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
                     else vm_wait<2>(bc[0][0], bc[0][1], bc[1][0], bc[1][1]);
                 }
-                if (!OAI_DBG_BIT(a, 8192) || t == 0) load_a(acur[1], t, 1);
-                if (!OAI_DBG_BIT(a, 4096)) {
+                load_a(acur[1], t, 1);
+                {
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -784,8 +763,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                             bn[k][n] = k == 0 ? (n == 0 ? gload16_asm<0>(wp, wlane) : gload16_asm<1024>(wp, wlane))
                                               : (n == 0 ? gload16_asm<2048>(wp, wlane) : gload16_asm<3072>(wp, wlane));
                 }
-                if (!OAI_DBG_BIT(a, 65536)) wp += STEP * 16;
-                if (!OAI_DBG_BIT(a, 32768)) {
+                wp += STEP * 16;
+                {
 #pragma unroll
                     for (int q = 0; q < pieces_in_tap(t); ++q) issue_piece(first_piece(t) + q, ch + 1);
                 }
@@ -797,7 +776,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
 #pragma unroll
                         for (int n = 0; n < NREP; ++n) acc[m][n] = mfma_16bit<true>(acur[0][m], __builtin_bit_cast(float4, bc[p][n]), acc[m][n]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < 9 && !OAI_DBG_BIT(a, 8192)) load_a(acur[0], t + 1, 0);
+                if (t + 1 < 9) load_a(acur[0], t + 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < ML; ++m)                             // a1.b0
@@ -842,20 +821,12 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
             if (it < it0 || it >= it1) continue;
             const int zc = it >> 1, yc = (it & 1) * (32 / TX);
             const int ozc = oz0 + zc, oy = oyl + yc;
-            if (!(OAI_EXP & 1) && cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
+            if (cok && ozc >= clo[0] && ozc < chi[0] && oy >= clo[1] && oy < chi[1] && oxl >= clo[2] && oxl < chi[2]) {
                 const unsigned uni = (unsigned)(((ozc * a.H + oy0 + yc) * a.W + ox0) * 64);                  // wave-uniform
                 float4* dstp = reinterpret_cast<float4*>(ob + (size_t)(lane_off + uni));
                 const float4 val = *reinterpret_cast<const float4*>(xb + (it * 256 + gtid) * 16);
-                if constexpr ((OAI_EXP & 32) != 0) *dstp = val;
-                else {
-                    __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
-                    __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
-                }
-                if constexpr ((OAI_EXP & 16) != 0) {
-                    asm volatile("" ::: "memory");
-                    __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
-                    __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
-                }
+                __builtin_nontemporal_store(val.x, &dstp->x); __builtin_nontemporal_store(val.y, &dstp->y);
+                __builtin_nontemporal_store(val.z, &dstp->z); __builtin_nontemporal_store(val.w, &dstp->w);
             }
         }
     };
@@ -949,7 +920,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
             const bool odd = ccol & 1;
             const unsigned sel = odd ? 0x03020706u : 0x05040100u;
 #pragma unroll
-            for (int r = 0; r < ((OAI_EXP & 4) ? 0 : 16); ++r) {
+            for (int r = 0; r < 16; ++r) {
                 // C/D row and 16-cout record of element r: 32x32 -- register r of the tile; 16x16 -- element i = r & 3 of tile (p, q) = (r >> 3, (r >> 2) & 1)
                 const int rr = M16 ? 16 * (r >> 3) + 4 * rq16 + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int qrec = M16 ? (r >> 2) & 1 : row >> 4;
@@ -1004,7 +975,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0][0]), "+v"(bq[0][0][1]), "+v"(bq[0][1][0]), "+v"(bq[0][1][1]),
                                  "+v"(bq[D - 1][0][0]), "+v"(bq[D - 1][0][1]), "+v"(bq[D - 1][1][0]), "+v"(bq[D - 1][1][1]) :: "memory");
             }
-            if constexpr (TY == 8 && NP == 4) if (a.pool_out && !(OAI_EXP & 2)) {       // (main shape only: the host asks for it where the box is whole blocks of it)
+            if constexpr (TY == 8 && NP == 4) if (a.pool_out) {       // (main shape only: the host asks for it where the box is whole blocks of it)
                 // MaxPool3d(2) fused (ec3 / ec5; networks.py:117,122), from the block's image: thread = (pooled voxel, 4 channels of one of the two
                 // 16-channel records); the pooled record keeps the (h0, h1) PAIR of the window's largest joined value -- the rule of
                 // maxpool2_sres_kernel (on equal values the pair with the larger h0: what splitting the fp32 maximum would have produced).
@@ -1362,7 +1333,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256 * NG * MS, ((OAI_EXP & 64) && N
             for (int ch = 0; ch < nchunks; ++ch) {
                 if (ch + 1 < nchunks) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!OAI_DBG_BIT(a, 16384)) stage_transform(ch + 1);
+                    stage_transform(ch + 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (ch + 2 < nchunks) stage_request(ch + 2);
                 }

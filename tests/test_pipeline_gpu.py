@@ -68,9 +68,11 @@ def test_stitch_reads_a_ragged_gather_buffer_in_place_on_the_device():
             if bounds[r + 1] > bounds[r]:
                 got = eng.segment_tiles(vol, tile, ovl, (bounds[r], bounds[r + 1]), crop_zyx=ovl, out=g.slot(r))    # computed straight into the slot
                 assert got.data_ptr() == g.slot(r).data_ptr()
-        assert torch.equal(g.compact(), compact)
+        # (block voxels inside the frame that stitch zeroes are not computed: they keep the NaN fill here and hold allocator garbage in `compact` --
+        #  the stitched maps are what must agree)
         assert torch.equal(eng.stitch(g, shape, tile, ovl, ovl), want), bounds
-        assert torch.isnan(buf).sum().item() == (world * stride - n) * eng.n_classes * eff[0] * eff[1] * eff[2]     # the tails were never written
+        for r in range(world):                                              # the tails of the slots were never written
+            assert torch.isnan(buf[r * stride + bounds[r + 1] - bounds[r]: (r + 1) * stride]).all()
     assert not torch.isnan(want).any()
 
 
