@@ -109,7 +109,7 @@ int oai_resample_through_disp(const float* prob_dev, int nzA, int nyA, int nxA,
  * double -- the value oai_phi_to_itk_displacement stores) is rebuilt at the 8 corners in registers, so neither the 71 MB
  * fp64 field nor a second pass over phi exists.  Results are bit-identical to oai_phi_to_itk_displacement +
  * oai_resample_through_disp per map.  Replaces the two deform_probmap calls of test/test_all.py:54-58 /
- * dask_processing.py:95-111.  out_dev[n_maps][nzB][nyB][nxB]. */
+ * dask_processing.py:95-111.  out_dev[n_maps][nzB][nyB][nxB].  nxA >= 2 (the two x corners of a row are one 8-byte gather). */
 int oai_resample_maps_through_phi(const float* probs_dev, int n_maps, int nzA, int nyA, int nxA,
                                   const float* phi_dev, int Dn, int Hn, int Wn,
                                   const oai_affine* b_index_to_net, const oai_affine* net_to_a_index,

@@ -542,20 +542,42 @@ resample_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
 // Algorithmic bytes per atlas voxel: NM x (4 read + 4 written) + 12 x (network voxels / atlas voxels) of phi.
 // One lane per atlas voxel, consecutive lanes = consecutive x; blocks are dealt to the 8 XCDs in contiguous z-runs so that a
 // source line of the near-identity map lands in one L2 (as in sample_kernel).
+// Round 6: the two x corners of a row are ONE 8-byte gather (x1 = x0 + 1 except at the clamped end of a row, where the pair starts one
+// element earlier and both corners select its upper half): 12 + 8 NM load instructions per voxel instead of 24 + 16 NM.  The kernel is
+// bound by the L1's request path (profiles/r05_registration.md: 413 MB in 0.44 ms = 0.12 of 8 TB/s), not by the fp64 chain or HBM; the
+// values loaded and every arithmetic operation on them are unchanged: bit-identical outputs.  Needs >= 2 elements per row (host check).
+struct PairSel { int base; bool lo_hi, hi_hi; };          // pair = p[base], p[base + 1]; corner x0 = lo_hi ? pair.y : pair.x, corner x1 = hi_hi ? pair.y : pair.x
+__device__ __forceinline__ PairSel pair_of(int x0, int x1, int n) {
+    const int base = min(x0, n - 2);
+    return PairSel{base, x0 != base, x1 != base};
+}
+__device__ __forceinline__ float2 load_pair(const float* p) {          // 4-byte aligned 8-byte load (global memory: unaligned dwordx2 is legal)
+    float2 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// Index arithmetic (round 6): a block is a run of kRsThreads voxels of ONE output row -- (row, x block) from the block id by wave-uniform
+// 32-bit divisions -- instead of a 64-bit linear index divided per lane, and the three fp64 reciprocals 1 / (n - 1) of the identity map
+// arrive as arguments (the host computes the same correctly rounded quotients): the kernel was bound by its own instruction count
+// (1117 per wave, a third of them integer and fp64 DIVISION sequences), not by memory (profiles/r06_registration.md).
+constexpr int kRsThreads = 128;
+struct RsInv { double inz, iny, inx; };
+
 template <int NM>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kRsThreads)
 resample_maps_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
                      const float* __restrict__ phi, int Dn, int Hn, int Wn,
-                     Affine b2n, Affine n2a, float* __restrict__ out, int nzB, int nyB, int nxB, long long nblocks) {
-    const long long per = (nblocks + 7) >> 3;
-    const long long logical = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((long long)(blockIdx.x >> 3) >= per || logical >= nblocks) return;
+                     Affine b2n, Affine n2a, float* __restrict__ out, int nzB, int nyB, int nxB, unsigned nblocks, unsigned nxblk, RsInv inv) {
+    const unsigned per = (nblocks + 7u) >> 3;
+    const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || logical >= nblocks) return;
+    const unsigned rowid = logical / nxblk, xblk = logical - rowid * nxblk;       // wave-uniform
+    const int zb = (int)(rowid / (unsigned)nyB), yb = (int)(rowid - (unsigned)zb * (unsigned)nyB);
+    const int xb = (int)(xblk * kRsThreads + threadIdx.x);
+    if (xb >= nxB) return;
     const long long n = (long long)nzB * nyB * nxB;
-    const long long i = logical * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const int xb = (int)(i % nxB);
-    const int yb = (int)((i / nxB) % nyB);
-    const int zb = (int)(i / ((long long)nxB * nyB));
+    const long long i = (long long)rowid * nxB + xb;
     double nx_, ny_, nz_;
     apply(b2n, (double)xb, (double)yb, (double)zb, nx_, ny_, nz_);
     const bool inside = nx_ >= -0.5 && nx_ < Wn - 0.5 && ny_ >= -0.5 && ny_ < Hn - 0.5 && nz_ >= -0.5 && nz_ < Dn - 0.5;
@@ -566,24 +588,31 @@ resample_maps_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
         clamp_split(ny_, Hn, y0, y1, fy);
         clamp_split(nz_, Dn, z0, z1, fz);
         const long long plane = (long long)Dn * Hn * Wn;
-        const double inz = 1.0 / (Dn - 1), iny = 1.0 / (Hn - 1), inx = 1.0 / (Wn - 1);
+        const double inz = inv.inz, iny = inv.iny, inx = inv.inx;
         const int o00 = (z0 * Hn + y0) * Wn, o01 = (z0 * Hn + y1) * Wn, o10 = (z1 * Hn + y0) * Wn, o11 = (z1 * Hn + y1) * Wn;
+        const PairSel ps = pair_of(x0, x1, Wn);
+        float2 q[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                          // all twelve pair loads first
+            const float* p = phi + (long long)(2 - c) * plane + ps.base;
+            q[c][0] = load_pair(p + o00); q[c][1] = load_pair(p + o01); q[c][2] = load_pair(p + o10); q[c][3] = load_pair(p + o11);
+        }
         double acc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {                          // ITK component c (x, y, z) = phi channel 2 - c (w, h, d)
-            const float* p = phi + (long long)(2 - c) * plane;
             const float sc = (float)((c == 0 ? Wn : c == 1 ? Hn : Dn) - 1);
             // identity coordinate of the corner along this component's axis: two values per axis
             const float ia = c == 0 ? identity_coord(x0, inx) : c == 1 ? identity_coord(y0, iny) : identity_coord(z0, inz);
             const float ib = c == 0 ? identity_coord(x1, inx) : c == 1 ? identity_coord(y1, iny) : identity_coord(z1, inz);
-            auto at = [&](int row, int xx, bool zhi, bool yhi, bool xhi) {
+            auto at = [&](int r, bool zhi, bool yhi, bool xhi) {
                 const float id = c == 0 ? (xhi ? ib : ia) : c == 1 ? (yhi ? ib : ia) : (zhi ? ib : ia);
-                return (double)((p[row + xx] - id) * sc);
+                const float v = xhi ? (ps.hi_hi ? q[c][r].y : q[c][r].x) : (ps.lo_hi ? q[c][r].y : q[c][r].x);
+                return (double)((v - id) * sc);
             };
-            const double c00 = at(o00, x0, 0, 0, 0) * (1 - fx) + at(o00, x1, 0, 0, 1) * fx;
-            const double c01 = at(o01, x0, 0, 1, 0) * (1 - fx) + at(o01, x1, 0, 1, 1) * fx;
-            const double c10 = at(o10, x0, 1, 0, 0) * (1 - fx) + at(o10, x1, 1, 0, 1) * fx;
-            const double c11 = at(o11, x0, 1, 1, 0) * (1 - fx) + at(o11, x1, 1, 1, 1) * fx;
+            const double c00 = at(0, 0, 0, 0) * (1 - fx) + at(0, 0, 0, 1) * fx;
+            const double c01 = at(1, 0, 1, 0) * (1 - fx) + at(1, 0, 1, 1) * fx;
+            const double c10 = at(2, 1, 0, 0) * (1 - fx) + at(2, 1, 0, 1) * fx;
+            const double c11 = at(3, 1, 1, 0) * (1 - fx) + at(3, 1, 1, 1) * fx;
             acc[c] = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
         }
         nx_ += acc[0]; ny_ += acc[1]; nz_ += acc[2];
@@ -600,21 +629,23 @@ resample_maps_kernel(const float* __restrict__ prob, int nzA, int nyA, int nxA,
         clamp_split(ay, nyA, y0, y1, fy);
         clamp_split(az, nzA, z0, z1, fz);
         const long long planeA = (long long)nzA * nyA * nxA;
-        const long long o00 = ((long long)z0 * nyA + y0) * nxA, o01 = ((long long)z0 * nyA + y1) * nxA;
-        const long long o10 = ((long long)z1 * nyA + y0) * nxA, o11 = ((long long)z1 * nyA + y1) * nxA;
-        float v[NM][8];
+        const PairSel ps = pair_of(x0, x1, nxA);
+        const long long o00 = ((long long)z0 * nyA + y0) * nxA + ps.base, o01 = ((long long)z0 * nyA + y1) * nxA + ps.base;
+        const long long o10 = ((long long)z1 * nyA + y0) * nxA + ps.base, o11 = ((long long)z1 * nyA + y1) * nxA + ps.base;
+        float2 v[NM][4];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {                           // all loads first: 8 x NM requests in flight per lane
+        for (int m = 0; m < NM; ++m) {                           // all loads first: 4 x NM pair requests in flight per lane
             const float* p = prob + m * planeA;
-            v[m][0] = p[o00 + x0]; v[m][1] = p[o00 + x1]; v[m][2] = p[o01 + x0]; v[m][3] = p[o01 + x1];
-            v[m][4] = p[o10 + x0]; v[m][5] = p[o10 + x1]; v[m][6] = p[o11 + x0]; v[m][7] = p[o11 + x1];
+            v[m][0] = load_pair(p + o00); v[m][1] = load_pair(p + o01); v[m][2] = load_pair(p + o10); v[m][3] = load_pair(p + o11);
         }
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            const double c00 = (double)v[m][0] * (1 - fx) + (double)v[m][1] * fx;
-            const double c01 = (double)v[m][2] * (1 - fx) + (double)v[m][3] * fx;
-            const double c10 = (double)v[m][4] * (1 - fx) + (double)v[m][5] * fx;
-            const double c11 = (double)v[m][6] * (1 - fx) + (double)v[m][7] * fx;
+            auto lo = [&](int k) { return (double)(ps.lo_hi ? v[m][k].y : v[m][k].x); };
+            auto hi = [&](int k) { return (double)(ps.hi_hi ? v[m][k].y : v[m][k].x); };
+            const double c00 = lo(0) * (1 - fx) + hi(0) * fx;
+            const double c01 = lo(1) * (1 - fx) + hi(1) * fx;
+            const double c10 = lo(2) * (1 - fx) + hi(2) * fx;
+            const double c11 = lo(3) * (1 - fx) + hi(3) * fx;
             r[m] = (float)((c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz);
         }
     }
@@ -764,14 +795,17 @@ int oai_resample_maps_through_phi(const float* probs, int n_maps, int nzA, int n
     OAI_CHECK_ARG(nzA > 0 && nyA > 0 && nxA > 0 && Dn > 1 && Hn > 1 && Wn > 1 && nzB > 0 && nyB > 0 && nxB > 0,
                   "oai_resample_maps_through_phi: bad sizes");
     OAI_CHECK_ARG((long long)Dn * Hn * Wn < (1LL << 31), "oai_resample_maps_through_phi: network grid too large");
+    OAI_CHECK_ARG(nxA >= 2, "oai_resample_maps_through_phi: maps need at least two voxels per row (the x corners are loaded as pairs)");
     Affine a, b;
     memcpy(&a, b2n, sizeof(Affine));
     memcpy(&b, n2a, sizeof(Affine));
-    const long long nblocks = ((long long)nzB * nyB * nxB + kThreads - 1) / kThreads;
-    OAI_CHECK_ARG(nblocks < (1LL << 31) - 8, "oai_resample_maps_through_phi: output grid too large");
+    const long long nxblk = (nxB + kRsThreads - 1) / kRsThreads;
+    const long long nblocks = (long long)nzB * nyB * nxblk;                       // one block = <= kRsThreads voxels of one output row
+    OAI_CHECK_ARG(nblocks < (1LL << 31) - 8 && (long long)nzB * nyB < (1LL << 31), "oai_resample_maps_through_phi: output grid too large");
     const unsigned grid = (unsigned)(((nblocks + 7) / 8) * 8);
     hipStream_t st = (hipStream_t)stream;
-#define OAI_RS(NM) resample_maps_kernel<NM><<<grid, kThreads, 0, st>>>(probs, nzA, nyA, nxA, phi, Dn, Hn, Wn, a, b, out, nzB, nyB, nxB, nblocks)
+    const RsInv inv{1.0 / (Dn - 1), 1.0 / (Hn - 1), 1.0 / (Wn - 1)};             // mermaidlite.identity_map's spacing, in double
+#define OAI_RS(NM) resample_maps_kernel<NM><<<grid, kRsThreads, 0, st>>>(probs, nzA, nyA, nxA, phi, Dn, Hn, Wn, a, b, out, nzB, nyB, nxB, (unsigned)nblocks, (unsigned)nxblk, inv)
     if (n_maps == 1) OAI_RS(1); else if (n_maps == 2) OAI_RS(2); else if (n_maps == 3) OAI_RS(3); else OAI_RS(4);
 #undef OAI_RS
     OAI_CHECK_LAUNCH();
