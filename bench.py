@@ -275,6 +275,16 @@ def dry_run(args, world, rank):
             if world > 1:
                 dist.all_reduce(total)
             assert int(total) == 4 * world and len(set(mine)) == len(mine)
+            # the per-rank streamed leg of the GPU run: each rank's [steady ms, volumes/s, GB/s out of pinned, GB/s into pinned] gathered to every rank
+            row = torch.tensor([130.0 + rank, 7.0, 40.0 + rank, 60.0], dtype=torch.float64)
+            rows = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(rows, row)
+            else:
+                rows = [row]
+            streamed = aggregate_streamed([r.tolist() for r in rows], resident_ms=129.0)
+            assert streamed["ranks"] == world and abs(streamed["steady_ms_per_volume"]["max"] - (130.0 + world - 1)) < 1e-9
+            assert abs(streamed["aggregate_steady_volumes_per_s"] - sum(1e3 / (130.0 + r) for r in range(world))) < 1e-9
         else:
             mine = parallel.volumes_for_rank(world * 2, rank, world)
             assert mine == [rank, rank + world]
@@ -287,9 +297,25 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "knee MRI volumes/sec (segment+register), 384x384x160 fp32", "value": None, "unit": "volumes/s",
                           "dry_run": True, "backend": "gloo" if world > 1 else None, "world_size": world, "n_gpus": 0,
                           "tile_ranges": [list(parallel.tile_range_for_rank(n_tiles, r, world, costs)) for r in range(world)] if args.mode == "tileshard" else None,
+                          "streamed_from_host": streamed if args.mode == "cohort" else None,
                           "mode": args.mode, "steps": args.steps, "warmup": args.warmup, "seconds": float(dt)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def aggregate_streamed(per_rank, resident_ms=None):
+    """The N > 1 form of `streamed_from_host` (--mode cohort): every rank streams its own volumes from ITS host memory through ITS GPU at the same
+    time -- N upload workers, N download workers and N x 5 clone threads on one host, N GPUs' PCIe links -- and reports [steady-state ms per
+    volume, volumes/s incl. fill and drain, out-of-pinned GB/s, into-pinned GB/s]; this is what rank 0 prints from the gathered rows.  The
+    aggregate is the SUM of the ranks' steady-state rates (independent units, no collective: SURVEY 8e), never `value`."""
+    steady = [r[0] for r in per_rank]
+    agg = sum(1e3 / ms for ms in steady if ms > 0)
+    return {"ranks": len(per_rank), "aggregate_steady_volumes_per_s": agg, "aggregate_volumes_per_s_incl_fill_drain": sum(r[1] for r in per_rank),
+            "steady_ms_per_volume": {"min": min(steady), "max": max(steady)},
+            "vs_resident": (resident_ms / max(steady)) if resident_ms else None,
+            "host_memcpy_GBps_per_rank": {"out_of_pinned_min": min(r[2] for r in per_rank), "into_pinned_min": min(r[3] for r in per_rank)},
+            "what": "every rank: volumes in pageable host memory -> pinned staging -> H2D -> segment + register + resample -> D2H -> caller-owned host tensors "
+                    "(cohort.CohortRunner), all ranks at once; resident = this run's ms_per_step"}
 
 
 def streamed_from_host(pipe, n_volumes=24, resident_ms=None):
@@ -380,7 +406,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in exact fp32 MFMA (full --steps) reported beside the primary")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity block (reference golden fixture)")
-    ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive leg (8 volumes streamed from host memory, BASELINE config 4)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive leg (volumes streamed from host memory, BASELINE config 4; --mode cohort: per rank, all ranks at once)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning option of the fp16x3 path (oai_unet_set_option, include/oai_hip.h); bit-preserving: sres, sres_mrep, sres_ring, "
                          "xcd_group, fuse_first, b_lds, wide, shared_enc, dead_stores, census; NOT bit-preserving: winograd (bit mask, default 19; "
@@ -503,6 +529,21 @@ def main():
     else:
         dt, conv_ms, conv_launches, overflow = measure(step, unet, args.steps, args.warmup, use_dist, dist)
         my_volumes = args.steps
+    streamed_rows = None
+    if args.mode == "cohort" and not args.no_streamed:
+        # (outside the timed region) every rank streams 12 volumes out of ITS host memory through CohortRunner at the same time: the first multi-GPU line
+        # then holds the resident rate (`value`) AND the streamed rate with N processes' host copies and PCIe traffic on one host (VERDICT r5 #4c)
+        if use_dist:
+            dist.barrier()
+        sf = streamed_from_host(pipe, n_volumes=12)
+        mine_row = torch.tensor([sf["steady_state"]["ms_per_volume"] if sf["steady_state"] else 0.0, sf["value"],
+                                 sf["host_memcpy"]["out_of_pinned_GBps"] or 0.0, sf["host_memcpy"]["into_pinned_GBps"] or 0.0], dtype=torch.float64, device="cuda")
+        if use_dist:
+            gathered = torch.zeros(world * 4, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(gathered, mine_row)
+            streamed_rows = gathered.view(world, 4).tolist()
+        else:
+            streamed_rows = [mine_row.tolist()]
     rank_ms = None
     if use_dist:
         # every rank's own wall time of the timed region (the barrier-bracketed region is the same for all; what differs is how long each
@@ -604,6 +645,8 @@ def main():
             out["registration_step_trees"] = icon_step_tree_times(A_net, B_net)
         if world == 1 and not args.no_streamed and args.mode == "replicas":
             out["streamed_from_host"] = streamed_from_host(pipe, resident_ms=1e3 * dt / args.steps)
+        if streamed_rows is not None:
+            out["streamed_from_host"] = aggregate_streamed(streamed_rows, resident_ms=1e3 * dt / args.steps)
         if world == 1 and not args.no_alt:
             # the SAME workload, same --steps / --warmup, with the other arithmetic (exact fp32 MFMA when the primary is split-fp16):
             # a first-class measurement, so that a reader who only credits reference-precision arithmetic has a number

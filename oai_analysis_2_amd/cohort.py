@@ -114,13 +114,18 @@ class CohortRunner:
 
     # ---- download side ----------------------------------------------------------------------------------------------------------------
     def _queue_d2h(self, res: VolumeResult, done: torch.cuda.Event) -> Tuple[int, torch.cuda.Event, tuple]:
-        """Launch thread: D2H of one volume's results on the download stream (after `done`) into a free pinned set.  Blocks only when both
-        sets are still being emptied (the download worker is more than a volume behind: back-pressure, not a steady-state wait)."""
+        """DOWNLOAD WORKER (round 6; rounds 4-5: the launch thread): wait ON THE HOST for the volume's compute (`done`), then issue the D2H of its
+        results on the download stream into a free pinned set.  Why not queue the copy behind `done` on the GPU as before: a stream that waits for an
+        event keeps a barrier packet at the head of its hardware queue for the whole volume (~130 ms), HIP deals its streams onto a few IN-ORDER
+        hardware queues, and whatever other stream shares that queue sits behind the barrier -- when it was the upload stream, the next volume's
+        upload-done marker (and with it the next volume's first kernel) waited for the previous volume's whole D2H: 7.3 ms per volume, or 3, or 0,
+        depending on how the streams had been dealt: the "bi-stable" 0.93-0.99 of the resident rate of round 5 (profiles/r06_cohort.md; with
+        GPU_MAX_HW_QUEUES=1 always 7.3 ms, with 2 never).  Issued only once `done` has fired, the copy never parks a barrier in any queue."""
+        done.synchronize()
         t0 = time.perf_counter()
         k = self._free_out.get()
         self.stats["launch_wait_s"] += time.perf_counter() - t0
         pins = self._pin_out[k]
-        self.down_stream.wait_event(done)
         names = _RESULT_NAMES + (("overflow",) if res.overflow is not None else ())
         with torch.cuda.stream(self.down_stream):
             for name in names:
@@ -154,9 +159,13 @@ class CohortRunner:
         finally:
             self._free_out.put(k)                                          # (the pinned buffers are reused by a later volume)
 
+    def _download(self, res: VolumeResult, done: torch.cuda.Event) -> Optional[VolumeResult]:
+        with torch.cuda.device(self.pipe.unet.device):
+            k, ev, keys = self._queue_d2h(res, done)
+            return self._collect(k, ev, keys, res.repeated_f32, res)
+
     def _download_async(self, res: VolumeResult, done: torch.cuda.Event) -> Future:
-        k, ev, keys = self._queue_d2h(res, done)
-        return self._down.submit(self._collect, k, ev, keys, res.repeated_f32, res)
+        return self._down.submit(self._download, res, done)
 
     def _finish(self, pending) -> VolumeResult:
         """Results of a queued volume whose download was started a volume ago; a volume whose fp16x3 segmentation left fp16's range is

@@ -157,6 +157,13 @@ def test_bench_spawns_its_own_ranks(mode, world):
     assert out["world_size"] == world and out["backend"] == "gloo" and out["dry_run"] and out["mode"] == mode and out["value"] is None
     if mode == "tileshard" and world == 8:
         assert [e - b for b, e in out["tile_ranges"]] == [23, 19, 19, 19, 19, 19, 19, 23]          # the split of profiles/r04_tileshard_projection.md
+    if mode == "cohort":
+        # VERDICT r5 #4c: the cohort line carries the PER-RANK streamed-from-host leg next to the resident rate -- here the gather + aggregation of
+        # the ranks' rows (steady ms, volumes/s, host GB/s) over gloo, with stand-in rows 130 + rank ms
+        sf = out["streamed_from_host"]
+        assert sf["ranks"] == world and sf["steady_ms_per_volume"] == {"min": 130.0, "max": 130.0 + world - 1}
+        assert abs(sf["aggregate_steady_volumes_per_s"] - sum(1e3 / (130.0 + r) for r in range(world))) < 1e-9
+        assert abs(sf["vs_resident"] - 129.0 / (130.0 + world - 1)) < 1e-12
     if world == 2:
         # without GPUs a real multi-GPU run must exit non-zero cleanly, before touching a device
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
