@@ -39,7 +39,7 @@ DTYPE_OF = {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 ter
             "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
             "fp16x3": "fp16x3 (every fp32 value held as 2 fp16 terms = 22 mantissa bits, 3 MFMA passes per product, fp32 accumulate; "
                       "fp32 in and out of every entry point; full-size parity vs the reference in `parity`)"}
-TRAFFIC_FILE = {"f32": "profiles/r05_pmc_traffic_f32.json", "fp16x3": "profiles/r05_pmc_traffic_sres.json"}
+TRAFFIC_FILE = {"f32": "profiles/r06_pmc_traffic_f32.json", "fp16x3": "profiles/r06_pmc_traffic_sres.json"}
 
 
 def physical_cores() -> int:

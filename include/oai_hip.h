@@ -246,6 +246,9 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *   "persistent" 0|1 (0) bit-preserving (round 5): the 64-cout Winograd layer (dc2) with ONE persistent workgroup per CU that pulls blocks from per-XCD counters
  *                       (a small plan kernel in front of every launch) while its staging waves run one block ahead.  Built for VERDICT r4 #1 (b) / (d); measured
  *                       +-0 ... +0.8 % per pass (profiles/r05_persistent.md): not the default
+ *   "up_nbw" 0..64 (0)  bit-preserving (round 6): column blocks of 256 a workgroup of the k2s2 up-conv kernel (networks.py:56,59,62) walks one after the other over its
+ *                       128 voxels -- the voxel table, the A-row plan and the workgroup launch are paid once per walk; 0 = as many as keep >= 16 workgroups per slot of
+ *                       the chip, 1 = one column block per workgroup (rounds 1-5), n = at most n
  *   "dead_stores" 0|1 (1) the encoder does not write the part of a skip tensor that the trimmed decoder never reads
  *   "census" 0|1 (1)    the kernels record per-layer activation maxima (activation exponents, LOW bit of the range flag)
  *   "calibrated" 0      forget that the activation exponents were calibrated (they keep their values): oai_unet_get_act_exponents reports 0 until

@@ -61,6 +61,7 @@ struct oai_unet {
     // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
     int act_exp[18] = {0};
     bool calibrated = false;
+    int opt_up_nbw = 0;                 // option "up_nbw": column blocks per workgroup of the k2s2 up-conv kernel: 0 = as many as keep >= 16 workgroups per slot, 1 = one (rounds 1-5), n = at most n
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
     int opt_wino = 19;                  // option "winograd": plain k3 layers with Cout % 64 == 0 run conv3_wino_sres (x axis in Winograd F(2,3) form: 2/3 of the MFMAs);
@@ -928,7 +929,15 @@ static int launch_up(const oai_unet* h, const Layer& L, const float* src, float*
     a.nnb = cdiv(8 * L.cout, 256);
     a.relu = 1;
     if (split && h->sres) {
-        unsigned grid = (unsigned)((size_t)ntiles * a.nmb * a.nnb);
+        // column blocks per workgroup (round 6): as many as leave >= 16 workgroups per workgroup slot of the chip (256 CUs x 2); narrow test networks
+        // (the dword-store path of the kernel) keep one; option "up_nbw": 0 = this rule, n = at most n
+        a.nbw = 1;
+        if (L.cout % 16 == 0 && h->opt_up_nbw > 1) a.nbw = std::min(h->opt_up_nbw, a.nnb);
+        else if (L.cout % 16 == 0 && h->opt_up_nbw == 0) {
+            a.nbw = a.nnb;
+            while (a.nbw > 1 && (size_t)ntiles * a.nmb * cdiv(a.nnb, a.nbw) < 8192) a.nbw = (a.nbw + 1) / 2;
+        }
+        unsigned grid = (unsigned)((size_t)ntiles * a.nmb * cdiv(a.nnb, a.nbw));
         if (h->xcd_group > 0) {                               // same dealing as the conv kernel's (launch_conv3_shape)
             a.nblocks = (int)grid; a.xcd_group = h->xcd_group;
             const unsigned q = 8u * (unsigned)h->xcd_group;
@@ -1396,6 +1405,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         // (A/B timing of the bookkeeping), so that the subnormal low-term loss cannot come back silently
         OAI_CHECK_ARG(value == 1 || h->calibrated, "oai_unet_set_option: census 0 needs a calibrated handle (activation exponents set)");
         h->opt_census = value;
+    } else if (!strcmp(name, "up_nbw")) {              // bit-preserving: column blocks a workgroup of the k2s2 up-conv walks (0 = automatic)
+        OAI_CHECK_ARG(value >= 0 && value <= 64, "oai_unet_set_option: up_nbw must be in [0, 64]");
+        h->opt_up_nbw = value;
     } else if (!strcmp(name, "calibrated")) {          // only clearing: setting goes through oai_unet_set_act_exponents / a settled oai_unet_calibrate_step
         OAI_CHECK_ARG(value == 0, "oai_unet_set_option: calibrated can only be cleared (0)");
         OAI_CHECK_ARG(h->opt_census == 1, "oai_unet_set_option: an uncalibrated handle needs the census (option census is 0)");

@@ -562,6 +562,7 @@ struct UpArgs {
     int reserved0 = 0;                  // (keeps the kernel-argument layout of earlier rounds)
     int nblocks = 0, xcd_group = 0;     // split-resident kernel: true workgroup count and the XCD dealing granularity (xcd_block_id): the column
                                         // blocks of one row block read the same A rows and should meet in one L2
+    int nbw = 1;                        // split-resident kernel: column blocks a workgroup walks one after the other (1 = one column block per workgroup)
 };
 
 // SPLIT = false: exact fp32 MFMA.  SPLIT = true: split-fp16, 3 passes (see conv3_igemm_bf16s): the A rows are split in

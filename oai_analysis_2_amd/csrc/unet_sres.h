@@ -1102,11 +1102,14 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;
     if (id < 0) return;
-    const int nb = id % a.nnb; id /= a.nnb;
+    // (round 6) a workgroup walks `nbw` column blocks of its 128 voxels one after the other: the voxel table, the A-row plan and the workgroup launch
+    // itself -- a quarter of dc3's time with one column block per workgroup (profiles/r02_conv_per_layer.md: "skeleton") -- are paid once per `nbw`,
+    // and the A rows of the later column blocks come out of a hot L2.  Same arithmetic per (voxel, column): bit-identical.
+    const int nbw = a.nbw > 0 ? a.nbw : 1, nnbg = (a.nnb + nbw - 1) / nbw;
+    const int nbg = id % nnbg; id /= nnbg;
     const int mb = id % a.nmb; id /= a.nmb;
     const int tile = id;
     const int N = 8 * a.Cout;
-    const int ncol0 = nb * 256 + wn * 128;
     const int row = lane & 31, half = lane >> 5;
     const int rz = a.hi[0] - a.lo[0], ry = a.hi[1] - a.lo[1], rx = a.hi[2] - a.lo[2];
     const int nvox = rz * ry * rx;
@@ -1145,6 +1148,15 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
                        srec(tile, nks, plane, 0, ((size_t)(a.lo[0] + z) * a.H + (a.lo[1] + y)) * a.W + (a.lo[2] + x)) + (((p & 3) ^ ((vl >> 2) & 3)) << 4);
         } else asrc[it] = nullptr;
     }
+    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + srec(tile, nco, 8 * plane, 0, 0);      // chunk c of output voxel v at + (c * 8 plane + v) * 64
+    const unsigned seen = census_peek(a.census);
+    unsigned umax = 0;
+    f32x16 acc[2][4];
+    bool looped = true;
+    int nb = nbg * nbw, ncol0 = nb * 256 + wn * 128;
+    for (int nbi = 0; nbi < nbw && nb < a.nnb; ++nbi, ++nb) {
+    ncol0 = nb * 256 + wn * 128;
+    if (nbi > 0) __syncthreads();                                           // everybody is done with the previous column block's image: the ring may be refilled
     const int ngroups = (N + 63) / 64;
     const unsigned char* bsrc[4];
 #pragma unroll
@@ -1160,7 +1172,6 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         for (int g = 0; g < 4; ++g)
             lds_dma16(bsrc[g] ? bsrc[g] + (size_t)ks * 4096 : a.zero, base + 8192 + g * 4096);
     };
-    f32x16 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1207,11 +1218,9 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         }
     }
     OAI_USTAMP(1);
-    unsigned char* outb = reinterpret_cast<unsigned char*>(a.out) + srec(tile, nco, 8 * plane, 0, 0);      // chunk c of output voxel v at + (c * 8 plane + v) * 64
     if (a.Cout % 16 == 0) {
         // ---- epilogue through LDS, one 64-voxel half (m) at a time: records [voxel 64][16 column chunks][64 B], copied out
         // 16 B per lane: every store instruction writes whole 64-byte records, 1 KiB per wave
-        float vmax = 0.0f;
         const int q = tid & 63;                                            // this thread's 16-byte piece of every voxel row
         const int cg = nb * 256 + (q >> 2) * 16;                             // first global column of its record
         const bool qok = cg < N;
@@ -1220,8 +1229,6 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
         const size_t inrow = (size_t)cchunk * 8 * plane * 64 + (q & 3) * 16;
         // this lane's four column scales / shifts, loaded ONCE here: inside the loops below hipcc waits for them with vmcnt(0), which in
         // the second half also drains the first half's sixteen copy-out stores all the way to memory
-        const unsigned seen = census_peek(a.census);
-        unsigned umax = 0;
         float scn[4], shn[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -1287,8 +1294,13 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
             }
             OAI_USTAMP(4);
         }
-        vmax = __builtin_bit_cast(float, umax);
-        census_note(a.census, a.range_flag, vmax, seen);
+        continue;                                                             // the next column block of this workgroup
+    }
+    looped = false;                                                           // (narrow network: nbw is 1, the store path below runs once)
+    break;
+    }
+    if (looped) {
+        census_note(a.census, a.range_flag, __builtin_bit_cast(float, umax), seen);
 #ifdef OAI_DIAG
         OAI_USTAMP(4);
         if (a.stamps && lane == 0) {
@@ -1298,6 +1310,7 @@ __global__ void __launch_bounds__(256, 2) upconv2_igemm_sres(const UpArgs a) {
 #endif
         return;
     }
+    const bool active = ncol0 < N;
     // ---- narrow test networks (Cout not a multiple of 16): dword stores straight from the accumulators
     if (!active) return;                                                  // (wave-uniform)
     {   // range census in a pass of its own over the accumulators (tracked inside the store loop below it cost 58 VGPRs and 168 B of scratch)

@@ -220,12 +220,13 @@ def test_fp16x3_reports_activations_outside_fp16_range():
 
 
 @pytest.mark.parametrize("opts", [{"sres_mrep": 2}, {"sres_ring": 1}, {"xcd_group": 0}, {"xcd_group": 7}, {"sres": 0}, {"fuse_first": 0}, {"b_lds": 1},
-                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}, {"persistent": 1}])
+                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}, {"persistent": 1}, {"up_nbw": 3}, {"up_nbw": 64}])
 def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     """The tuning variants of the default path (2 z slices per block, the six-slot plane ring, other XCD dealings, fp32-resident
     activations, ec0 as its own launch instead of inside ec1's halo staging, weight fragments through the workgroup's LDS ring, the
     8-wave double-buffered kernel of the Cout % 128 == 0 layers off / forced also for small launches, skip tensors written in full,
-    no range census, ec0 -> ec1 per tile instead of once over the padded volume + a shell per tile) accumulate in the same k order: identical stitched maps, and the golden tolerance of the default.
+    no range census, ec0 -> ec1 per tile instead of once over the padded volume + a shell per tile, the k2s2 up-conv's workgroups walking three / all column blocks
+    instead of one -- the small volume's automatic choice) accumulate in the same k order: identical stitched maps, and the golden tolerance of the default.
     "winograd" (the x axis of the plain layers in Winograd F(2,3) form; default 19 = both cout classes, the two-group form on 16x16x32 tap pairs; 3 = both on 32x32x16; bit 5 = the 64-cout layer on them too) against the direct form (0): same precision, other rounding points.
     "m16" 0 (round 5): the direct kernel of the layers with Cout % 128 != 0 on 32x32x16 taps instead of 16x16x32 tap pairs -- other rounding points too; the plane ring and the
     weight ring exist in the 32x32x16 form only and are compared there."""
