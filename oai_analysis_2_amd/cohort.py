@@ -41,9 +41,18 @@ class CohortRunner:
     LAG = 2
     N_OUT_SETS = LAG + 1           # pinned result sets: one per volume whose download may be in flight or being emptied
 
-    def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False, high_priority_compute: bool = False, board=None):
+    def __init__(self, pipeline: VolumePipeline, keep_on_device: bool = False, high_priority_compute: bool = False, board=None, result_pool: int = 0):
         self.pipe = pipeline
         self.keep_on_device = keep_on_device
+        # result_pool = n > 0: results are handed out in RECYCLED host tensors -- a ring of n result sets, faulted in once -- instead of freshly allocated
+        # ones: nine tenths of the download leg are the page faults of 566 MB of fresh memory per volume (profiles/r06_cohort.md, scripts/host8.py: 58 ms
+        # against 15 ms per volume with eight processes on one host).  The caller must be done with a result before n more have been yielded (n >= LAG + 2).
+        # 0 (default): every result is memory the caller owns for good, as the reference's per-task returns are (dask_processing.py:170-181).
+        if result_pool and result_pool < self.LAG + 2:
+            raise ValueError(f"result_pool must be 0 or >= {self.LAG + 2}")
+        self.result_pool = int(result_pool)
+        self._pool_sets: List[dict] = [dict() for _ in range(self.result_pool)]
+        self._pool_next = 0
         # parallel.CalibrationBoard of a multi-rank cohort (process_cohort): when a sidecar's fp16x3 calibration is dropped for not fitting the
         # data, ONE rank recalibrates and every rank takes that outcome -- polled before each volume is queued, never a blocking collective
         self.board = board
@@ -150,7 +159,15 @@ class CohortRunner:
             if len(keys) > 5 and int(pins[keys[5]][0]):
                 return None
             t0 = time.perf_counter()
-            outs = list(self._clone.map(lambda key: torch.empty(pins[key].shape, dtype=pins[key].dtype).copy_(pins[key]), keys[:5]))
+            if self.result_pool:
+                dst = self._pool_sets[self._pool_next]                     # (only the download worker touches the ring)
+                self._pool_next = (self._pool_next + 1) % self.result_pool
+                for key in keys[:5]:
+                    if key not in dst:
+                        dst[key] = torch.empty(pins[key].shape, dtype=pins[key].dtype)
+                outs = list(self._clone.map(lambda key: dst[key].copy_(pins[key]), keys[:5]))
+            else:
+                outs = list(self._clone.map(lambda key: torch.empty(pins[key].shape, dtype=pins[key].dtype).copy_(pins[key]), keys[:5]))
             dt = time.perf_counter() - t0
             with self._lock:
                 self.stats["clone_bytes"] += sum(o.numel() * o.element_size() for o in outs)

@@ -139,6 +139,25 @@ def test_cohort_of_8_full_size_volumes_streams_and_matches_single_runs():
     assert seen == list(range(8))
 
 
+def test_cohort_results_in_recycled_host_buffers_equal_fresh_ones():
+    """``CohortRunner(result_pool=n)``: the same results, handed out in a ring of n pre-faulted host result sets (the download leg is 90 % page faults of
+    fresh memory: profiles/r06_cohort.md); a result stays valid until n more have been yielded; n below LAG + 2 is refused."""
+    from oai_analysis_2_amd.cohort import CohortRunner
+    pipe, shape = _small_pipe(make_unet_state_dict(1, width_div=2))
+    imgs = [Image(make_volume(20 + i, shape), [0.36, 0.37, 0.7], [1.0, 2.0, 3.0]) for i in range(9)]
+    fresh = {i: r for i, r in CohortRunner(pipe).run(imgs)}
+    with pytest.raises(ValueError):
+        CohortRunner(pipe, result_pool=2)
+    runner = CohortRunner(pipe, result_pool=4)
+    seen = {}
+    for i, r in runner.run(imgs):
+        for name in ("fc", "tc", "phi", "fc_atlas", "tc_atlas"):
+            assert torch.equal(getattr(r, name), getattr(fresh[i], name)), (i, name)
+        seen[i] = r.fc.data_ptr()
+    assert len(set(seen.values())) == 4                                   # four recycled sets, not nine allocations
+    assert seen[0] == seen[4] == seen[8] and seen[1] == seen[5]
+
+
 def test_registration_under_the_segmentation_equals_registration_alone():
     """The overlapped pipeline runs the ICON kernels on a side stream UNDERNEATH the MFMA convolution kernels.  Alternating two
     full-size volumes, phi of every overlapped run must be bit-identical to the registration run alone (nothing else on the GPU).
