@@ -34,3 +34,22 @@ def test_run_sharded_equals_run_under_an_rccl_process_group_of_one():
     assert out["calibrated"] and len(out["exponents"]) == 18
     assert out["equal"], "run_sharded differs from run under the process group"
     assert out["flag"] == 0 and out["fc_sum"] > 0
+
+
+def test_run_sharded_at_world_2_on_one_gpu_over_gloo():
+    """the sharded path had never run between two processes on GPU memory (the box has one MI355X and RCCL does not put two
+    ranks on one device).  Two ranks on device 0 with the gloo backend on DEVICE tensors: broadcast of the volume, cost-balanced tile ranges
+    computed straight into the gather buffer's slots, the in-place ragged all_gather, ``oai_stitch_blocks_ranged`` over a two-range slot table,
+    the MAX-reduced range state, the z-slab gather -- and every rank's ``run_sharded`` result equals its own ``run``."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OAI_TEST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world"] == 2 and out["backend"] == "gloo"
+    assert out["tile_ranges"][0][1] == out["tile_ranges"][1][0] and out["tile_ranges"][1][1] == out["n_tiles"] == 75
+    assert out["equal"] and out["equal_on_every_rank"], "run_sharded differs from run at world 2"
+    assert out["flag"] == 0 and out["fc_sum"] > 0
+
