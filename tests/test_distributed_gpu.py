@@ -53,3 +53,19 @@ def test_run_sharded_at_world_2_on_one_gpu_over_gloo():
     assert out["equal"] and out["equal_on_every_rank"], "run_sharded differs from run at world 2"
     assert out["flag"] == 0 and out["fc_sum"] > 0
 
+
+def test_process_cohort_at_world_2_on_one_gpu_over_gloo(tmp_path):
+    """``dask_processing.process_cohort`` -- the driver that replaces the reference's Dask graph (dask_processing.py:46-189) -- between two real
+    processes: one shared volume queue (every volume claimed exactly once), one calibration for the group through the store, a streaming
+    CohortRunner per rank; and a volume's results do not depend on the rank that claimed it: each equals the same volume run alone on rank 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OAI_TEST_DIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_cohort_worker_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["world"] == 2 and out["calibrated"] and out["same_calibration"]
+    claimed = sorted(i for c in out["claimed"] for i in c)
+    assert claimed == list(range(7)), out["claimed"]                       # every volume exactly once, whatever the split
+    assert all(out["match_alone"].values()), out["match_alone"]
+
