@@ -246,6 +246,9 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *   "persistent" 0|1 (0) bit-preserving (round 5): the 64-cout Winograd layer (dc2) with ONE persistent workgroup per CU that pulls blocks from per-XCD counters
  *                       (a small plan kernel in front of every launch) while its staging waves run one block ahead.  Built for VERDICT r4 #1 (b) / (d); measured
  *                       +-0 ... +0.8 % per pass (profiles/r05_persistent.md): not the default
+ *   "first_blocks" 1..4096 (24) bit-preserving (round 6): workgroups per tile of the ec0 kernel (networks.py:43 where it is not fused into ec1's staging: the 3-voxel
+ *                       shell of every tile, the fp16x3 path without fuse_first); each walks the tile's voxel pairs with a grid stride, the next pair's 36 inputs
+ *                       gathered under the current pair's FMAs (2.17 -> 1.38 ms per 160 tiles)
  *   "up_nbw" 0..64 (0)  bit-preserving (round 6): column blocks of 256 a workgroup of the k2s2 up-conv kernel (networks.py:56,59,62) walks one after the other over its
  *                       128 voxels -- the voxel table, the A-row plan and the workgroup launch are paid once per walk; 0 = as many as keep >= 16 workgroups per slot of
  *                       the chip, 1 = one column block per workgroup (rounds 1-5), n = at most n

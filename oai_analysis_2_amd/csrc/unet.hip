@@ -61,6 +61,7 @@ struct oai_unet {
     // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
     int act_exp[18] = {0};
     bool calibrated = false;
+    int opt_first_blocks = 24;          // option "first_blocks": workgroups per tile of the ec0 kernel conv3_first_sres_kernel (each walks the tile's voxel pairs with a grid stride, the next pair's gathers under the current pair's FMAs)
     int opt_up_nbw = 0;                 // option "up_nbw": column blocks per workgroup of the k2s2 up-conv kernel: 0 = as many as keep >= 16 workgroups per slot, 1 = one (rounds 1-5), n = at most n
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
     int opt_wide = 1;                   // option "wide": layers with Cout % 128 == 0 run conv3_igemm_sres2 (one 8-wave workgroup per CU, double-buffered halo)
@@ -1067,7 +1068,7 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
         }
         {   // ec0 where ec1's shell reads it: closer than 3 voxels to a face (voxel pairs along x, enumerated slab by slab)
             const size_t pairs = (size_t)6 * d[0][1] * (d[0][2] / 2) + (size_t)(d[0][0] - 6) * 6 * (d[0][2] / 2) + (size_t)(d[0][0] - 6) * (d[0][1] - 6) * 4;
-            dim3 grid(cdiv(pairs, 256), n);
+            dim3 grid(std::min<unsigned>(cdiv(pairs, 256), (unsigned)h->opt_first_blocks), n);
             conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, L[EC0].scale_f16, L[EC0].shift_f16, reinterpret_cast<unsigned char*>(buf[B_E0]), 1,
                                                               h->range_flag, h->opt_census ? h->census + 16 * EC0 : nullptr, 3);
             OAI_CHECK_LAUNCH();
@@ -1089,7 +1090,8 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
     const bool fuse_first = first_fusable(h, need[EC1]);
     const TileSource* fsrc = fuse_first ? &src : nullptr;
     if (!fuse_first) {   // ec0 (+ gather)
-        dim3 grid(cdiv(v0 / 2, 256), n);
+        const dim3 grid_all(cdiv(v0 / 2, 256), n);                                          // one workgroup per 256 voxel pairs (the fp32 kernel)
+        const dim3 grid(std::min<unsigned>(cdiv(v0 / 2, 256), (unsigned)h->opt_first_blocks), n);     // the split-resident kernel walks the pairs with a grid stride
         const int c = L[EC0].cout;
         unsigned char* e0s = reinterpret_cast<unsigned char*>(buf[B_E0]);
         const bool f16 = h->precision == OAI_PREC_FP16X3;
@@ -1099,9 +1101,9 @@ static int run_batch(oai_unet* h, const TileSource& src, int n, const Box need[1
         if (h->sres && c == 32) conv3_first_sres_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0, 0);
         else if (h->sres && c == 16) conv3_first_sres_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0, 0);
         else if (h->sres && c == 8) conv3_first_sres_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, e0s, 1, h->range_flag, cen0, 0);
-        else if (c == 32) conv3_first_kernel<32><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
-        else if (c == 16) conv3_first_kernel<16><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
-        else if (c == 8) conv3_first_kernel<8><<<grid, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
+        else if (c == 32) conv3_first_kernel<32><<<grid_all, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
+        else if (c == 16) conv3_first_kernel<16><<<grid_all, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
+        else if (c == 8) conv3_first_kernel<8><<<grid_all, 256, 0, st>>>(src, L[EC0].plain, sc0, sh0, buf[B_E0], 1);
         else return set_error(OAI_ERR_ARG, "ec0 cout %d unsupported (8, 16 or 32)", c);
         OAI_CHECK_LAUNCH();
     }
@@ -1405,6 +1407,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         // (A/B timing of the bookkeeping), so that the subnormal low-term loss cannot come back silently
         OAI_CHECK_ARG(value == 1 || h->calibrated, "oai_unet_set_option: census 0 needs a calibrated handle (activation exponents set)");
         h->opt_census = value;
+    } else if (!strcmp(name, "first_blocks")) {        // bit-preserving: workgroups per tile of the ec0 kernel (grid stride over the tile's voxel pairs)
+        OAI_CHECK_ARG(value >= 1 && value <= 4096, "oai_unet_set_option: first_blocks must be in [1, 4096]");
+        h->opt_first_blocks = value;
     } else if (!strcmp(name, "up_nbw")) {              // bit-preserving: column blocks a workgroup of the k2s2 up-conv walks (0 = automatic)
         OAI_CHECK_ARG(value >= 0 && value <= 64, "oai_unet_set_option: up_nbw must be in [0, 64]");
         h->opt_up_nbw = value;

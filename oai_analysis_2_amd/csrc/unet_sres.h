@@ -1359,26 +1359,32 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
                                                                const float* __restrict__ shift, unsigned char* __restrict__ out, int relu,
                                                                int* __restrict__ range_flag, unsigned* __restrict__ census, int shell) {
     // shell > 0: only voxels closer than `shell` to a face of the tile are computed (the rest of ec0 comes from the pass over the whole
-    // volume, see run_batch); the exit below is per thread, behind the barrier
+    // volume, see run_batch).
+    // Round 6: a workgroup WALKS its tile's voxel pairs with a grid stride (the host launches option "first_blocks" = 24 workgroups per tile), and the 36 inputs
+    // of the NEXT pair are gathered while the current pair's 1 728 FMAs run.  The counters had shown the VALU 35 % busy at 2.5 waves per SIMD
+    // (profiles/r06_ec1_shell.md): a wave's life was a gather round trip out of L2 / HBM, then its FMAs, then its stores, with too few waves per SIMD to
+    // cover one another -- neither the store pattern, nor the instruction count, nor the LDS weight reads moved the time.  Same fmaf chains: bit-identical.
     __shared__ __attribute__((aligned(16))) float wl[27 * COUT];
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) wl[i] = wk[i];
     __syncthreads();
     const size_t plane = (size_t)s.td * s.th * s.tw;
     const int local_tile = blockIdx.y;
     const int hw = s.tw >> 1;
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int x, y, z;
-    bool live;
-    if (shell <= 0) {
-        live = p < plane / 2;
-        x = 2 * (int)(p % hw); y = (int)((p / hw) % s.th); z = (int)(p / ((size_t)hw * s.th));
-    } else {
-        // only the voxel pairs closer than `shell` to a face, enumerated slab by slab (see first_shell_pairs): two z slabs of `shell`
-        // slices, between them two y slabs of `shell` rows, between those the first and last ceil(shell / 2) x pairs of every row
-        const int sh2 = 2 * shell, ps = (shell + 1) / 2;
-        const size_t nA = (size_t)sh2 * s.th * hw, nB = (size_t)(s.td - sh2) * sh2 * hw, nC = (size_t)(s.td - sh2) * (s.th - sh2) * 2 * ps;
-        live = p < nA + nB + nC;
-        if (p < nA) {
+    const int sh2 = 2 * shell, ps = (shell + 1) / 2;
+    const size_t nA = shell > 0 ? (size_t)sh2 * s.th * hw : 0, nB = shell > 0 ? (size_t)(s.td - sh2) * sh2 * hw : 0;
+    const size_t npairs = shell <= 0 ? plane / 2 : nA + nB + (size_t)(s.td - sh2) * (s.th - sh2) * 2 * ps;
+    int tk = 0, tj = 0, ti = 0;
+    if (s.vol) {
+        const int t = s.tile_begin + local_tile;
+        tk = t % s.gx; tj = (t / s.gx) % s.gy; ti = t / (s.gx * s.gy);
+    }
+    const float* const base = s.vol ? s.vol : s.tiles + (size_t)local_tile * plane;
+    // voxel pair p -> (x even, y, z); shell mode: the pairs closer than `shell` to a face, enumerated slab by slab (see first_shell_pairs): two z slabs of
+    // `shell` slices, between them two y slabs of `shell` rows, between those the first and last ceil(shell / 2) x pairs of every row
+    auto decode = [&](size_t p, int& x, int& y, int& z) __attribute__((always_inline)) {
+        if (shell <= 0) {
+            x = 2 * (int)(p % hw); y = (int)((p / hw) % s.th); z = (int)(p / ((size_t)hw * s.th));
+        } else if (p < nA) {
             const int zi = (int)(p / ((size_t)s.th * hw));
             z = zi < shell ? zi : s.td - sh2 + zi; y = (int)((p / hw) % s.th); x = 2 * (int)(p % hw);
         } else if (p < nA + nB) {
@@ -1386,102 +1392,98 @@ __global__ void __launch_bounds__(256) conv3_first_sres_kernel(const TileSource 
             const int yi = (int)((q / hw) % sh2);
             z = shell + (int)(q / ((size_t)sh2 * hw)); y = yi < shell ? yi : s.th - sh2 + yi; x = 2 * (int)(q % hw);
         } else {
-            const size_t q = live ? p - nA - nB : 0;
+            const size_t q = p - nA - nB;
             const int xi = (int)(q % (2 * ps));
             z = shell + (int)(q / ((size_t)(s.th - sh2) * 2 * ps)); y = shell + (int)((q / (2 * ps)) % (s.th - sh2));
             x = xi < ps ? 2 * xi : s.tw - 2 * ps + 2 * (xi - ps);
         }
-    }
-    const bool inner = !live;
-    int iz[3], iy[3], ix[4];
-    const float* base;
-    if (s.vol) {
-        const int t = s.tile_begin + local_tile;
-        const int tk = t % s.gx, tj = (t / s.gx) % s.gy, ti = t / (s.gx * s.gy);
+    };
+    // the 3 x 3 x 4 inputs of the pair at (x, y, z): Partition's reflect-padded gather out of the volume, or the tile tensor; outside the tile: Conv3d's zeros
+    auto gather = [&](int x, int y, int z, float (&inr)[9][4]) __attribute__((always_inline)) {
+        int iz[3], iy[3], ix[4];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int zz = z + d - 1, yy = y + d - 1;
-            iz[d] = (unsigned)zz < (unsigned)s.td ? reflect_index(ti * s.ez + zz - s.oz, s.D) * s.H * s.W : -1;
-            iy[d] = (unsigned)yy < (unsigned)s.th ? reflect_index(tj * s.ey + yy - s.oy, s.H) * s.W : -1;
+            if (s.vol) {
+                iz[d] = (unsigned)zz < (unsigned)s.td ? reflect_index(ti * s.ez + zz - s.oz, s.D) * s.H * s.W : -1;
+                iy[d] = (unsigned)yy < (unsigned)s.th ? reflect_index(tj * s.ey + yy - s.oy, s.H) * s.W : -1;
+            } else {
+                iz[d] = (unsigned)zz < (unsigned)s.td ? zz * s.th * s.tw : -1;
+                iy[d] = (unsigned)yy < (unsigned)s.th ? yy * s.tw : -1;
+            }
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int xx = x + d - 1;
-            ix[d] = (unsigned)xx < (unsigned)s.tw ? reflect_index(tk * s.ex + xx - s.ox, s.W) : -1;
-        }
-        base = s.vol;
-    } else {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int zz = z + d - 1, yy = y + d - 1;
-            iz[d] = (unsigned)zz < (unsigned)s.td ? zz * s.th * s.tw : -1;
-            iy[d] = (unsigned)yy < (unsigned)s.th ? yy * s.tw : -1;
+            if (s.vol) ix[d] = (unsigned)xx < (unsigned)s.tw ? reflect_index(tk * s.ex + xx - s.ox, s.W) : -1;
+            else ix[d] = (unsigned)xx < (unsigned)s.tw ? xx : -1;
         }
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int xx = x + d - 1;
-            ix[d] = (unsigned)xx < (unsigned)s.tw ? xx : -1;
+        for (int zy = 0; zy < 9; ++zy) {
+            const int a = iz[zy / 3], b = iy[zy % 3];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) inr[zy][d] = (a | b | ix[d]) >= 0 ? base[(size_t)a + b + ix[d]] : 0.0f;
         }
-        base = s.tiles + (size_t)local_tile * plane;
-    }
+    };
     float rmax = 0.0f;
-    if (!inner) {
-    float acc[2][COUT];
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int x = 0, y = 0, z = 0;
+    float inn[9][4];
+    if (p < npairs) { decode(p, x, y, z); gather(x, y, z, inn); }
+    while (p < npairs) {
+        float inr[9][4];
 #pragma unroll
-    for (int j = 0; j < COUT; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
-    // all 36 inputs of the voxel pair in flight before the first FMA (round 5): loaded inside the loop below -- it is not unrolled: 864 FMAs per
-    // iteration -- every one of its nine iterations began with an exposed memory round trip (the shell pass of ec0: 2.17 ms for 38 GFLOP)
-    float inr[9][4];
+        for (int zy = 0; zy < 9; ++zy)
 #pragma unroll
-    for (int zy = 0; zy < 9; ++zy) {
-        const int a = iz[zy / 3], b = iy[zy % 3];
+            for (int d = 0; d < 4; ++d) inr[zy][d] = inn[zy][d];
+        const size_t v = ((size_t)z * s.th + y) * s.tw + x;
+        p += stride;
+        if (p < npairs) { decode(p, x, y, z); gather(x, y, z, inn); }      // the next pair's inputs: in flight under this pair's FMAs
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[2][COUT];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) inr[zy][d] = (a | b | ix[d]) >= 0 ? base[(size_t)a + b + ix[d]] : 0.0f;
-    }
+        for (int j = 0; j < COUT; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; }
 #pragma unroll
-    for (int zy = 0; zy < 9; ++zy) {
-        float in[4];
+        for (int zy = 0; zy < 9; ++zy) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) in[d] = inr[zy][d];
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* w = &wl[(zy * 3 + dx) * COUT];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const float* w = &wl[(zy * 3 + dx) * COUT];
+                for (int j = 0; j < COUT; j += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(w + j);
+                    acc[0][j] = fmaf(inr[zy][dx], w4.x, acc[0][j]);         acc[1][j] = fmaf(inr[zy][dx + 1], w4.x, acc[1][j]);
+                    acc[0][j + 1] = fmaf(inr[zy][dx], w4.y, acc[0][j + 1]); acc[1][j + 1] = fmaf(inr[zy][dx + 1], w4.y, acc[1][j + 1]);
+                    acc[0][j + 2] = fmaf(inr[zy][dx], w4.z, acc[0][j + 2]); acc[1][j + 2] = fmaf(inr[zy][dx + 1], w4.z, acc[1][j + 2]);
+                    acc[0][j + 3] = fmaf(inr[zy][dx], w4.w, acc[0][j + 3]); acc[1][j + 3] = fmaf(inr[zy][dx + 1], w4.w, acc[1][j + 3]);
+                }
+            }
+        }
+        constexpr int NCH = (COUT + 15) / 16;
 #pragma unroll
-            for (int j = 0; j < COUT; j += 4) {
-                const float4 w4 = *reinterpret_cast<const float4*>(w + j);
-                acc[0][j] = fmaf(in[dx], w4.x, acc[0][j]);         acc[1][j] = fmaf(in[dx + 1], w4.x, acc[1][j]);
-                acc[0][j + 1] = fmaf(in[dx], w4.y, acc[0][j + 1]); acc[1][j + 1] = fmaf(in[dx + 1], w4.y, acc[1][j + 1]);
-                acc[0][j + 2] = fmaf(in[dx], w4.z, acc[0][j + 2]); acc[1][j + 2] = fmaf(in[dx + 1], w4.z, acc[1][j + 2]);
-                acc[0][j + 3] = fmaf(in[dx], w4.w, acc[0][j + 3]); acc[1][j + 3] = fmaf(in[dx + 1], w4.w, acc[1][j + 3]);
+        for (int vv = 0; vv < 2; ++vv) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                unsigned char* o = out + srec(local_tile, NCH, plane, ch, v + vv);
+                u16x8 hi[2], lo[2];                                  // the whole 64-byte record in registers: four 16-byte stores
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int c = ch * 16 + j;
+                    float r = 0.0f;
+                    if (c < COUT) { r = acc[vv][c < COUT ? c : 0] * scale[c < COUT ? c : 0] + shift[c < COUT ? c : 0]; if (relu) r = fmaxf(r, 0.0f); }
+                    rmax = fmaxf(rmax, fabsf(r));
+                    unsigned l;
+                    hi[j >> 3][j & 7] = (unsigned short)split2_f16(r, l);
+                    lo[j >> 3][j & 7] = (unsigned short)l;
+                }
+                *reinterpret_cast<u16x8*>(o) = hi[0];
+                *reinterpret_cast<u16x8*>(o + 16) = hi[1];
+                *reinterpret_cast<u16x8*>(o + 32) = lo[0];
+                *reinterpret_cast<u16x8*>(o + 48) = lo[1];
             }
         }
     }
-    constexpr int NCH = (COUT + 15) / 16;
-    const size_t v = ((size_t)z * s.th + y) * s.tw + x;
-#pragma unroll
-    for (int vv = 0; vv < 2; ++vv) {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            unsigned char* o = out + srec(local_tile, NCH, plane, ch, v + vv);
-            u16x8 hi[2], lo[2];                                  // the whole 64-byte record in registers: four 16-byte stores
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int c = ch * 16 + j;
-                float r = 0.0f;
-                if (c < COUT) { r = acc[vv][c < COUT ? c : 0] * scale[c < COUT ? c : 0] + shift[c < COUT ? c : 0]; if (relu) r = fmaxf(r, 0.0f); }
-                rmax = fmaxf(rmax, fabsf(r));
-                unsigned l;
-                hi[j >> 3][j & 7] = (unsigned short)split2_f16(r, l);
-                lo[j >> 3][j & 7] = (unsigned short)l;
-            }
-            *reinterpret_cast<u16x8*>(o) = hi[0];
-            *reinterpret_cast<u16x8*>(o + 16) = hi[1];
-            *reinterpret_cast<u16x8*>(o + 32) = lo[0];
-            *reinterpret_cast<u16x8*>(o + 48) = lo[1];
-        }
-    }
-    }
-    census_note(census, range_flag, rmax);      // (whole blocks leave at the top: plane / 2 is a multiple of 256)
+    census_note(census, range_flag, rmax);
 }
 
 // ---- MaxPool3d(2) on format S (fallback when the pooling cannot ride in the conv epilogue) -----------------------------------

@@ -228,7 +228,7 @@ class UNetEngine:
 
     def set_option(self, name: str, value: int) -> None:
         """Tuning options of the fp16x3 path (include/oai_hip.h: oai_unet_set_option).  Bit-preserving (same k order, same maps):
-        "sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census", "up_nbw".
+        "sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census", "up_nbw", "first_blocks".
         NOT bit-preserving: "winograd" (bit mask, default 19: the x axis of ten layers in Winograd F(2,3) form, bit 4 = 16x16x32 tap pairs -- other rounding,
         same parity gates; 0 = the direct form everywhere), "winograd_layers" (which layers), "m16" (default 1: the direct kernel of the layers with
         Cout % 128 != 0 on 16x16x32 tap pairs), "m16_layers" and "persistent" (default 0: dc2 with persistent workgroups, bit-identical, not faster)."""

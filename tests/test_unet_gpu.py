@@ -220,7 +220,7 @@ def test_fp16x3_reports_activations_outside_fp16_range():
 
 
 @pytest.mark.parametrize("opts", [{"sres_mrep": 2}, {"sres_ring": 1}, {"xcd_group": 0}, {"xcd_group": 7}, {"sres": 0}, {"fuse_first": 0}, {"b_lds": 1},
-                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}, {"persistent": 1}, {"up_nbw": 3}, {"up_nbw": 64}])
+                                  {"wide": 0}, {"wide": 2}, {"dead_stores": 0}, {"census": 0}, {"shared_enc": 0}, {"winograd": 1}, {"winograd": 2}, {"winograd": 3}, {"winograd": 7}, {"winograd": 11}, {"winograd": 17}, {"winograd": 19}, {"winograd": 34}, {"winograd": 51}, {"m16": 0}, {"persistent": 1}, {"up_nbw": 3}, {"up_nbw": 64}, {"first_blocks": 1}, {"first_blocks": 4096}])
 def test_split_fp16_kernel_variants_agree(golden_dir, opts):
     """The tuning variants of the default path (2 z slices per block, the six-slot plane ring, other XCD dealings, fp32-resident
     activations, ec0 as its own launch instead of inside ec1's halo staging, weight fragments through the workgroup's LDS ring, the
