@@ -5,6 +5,9 @@ segmenter and the ICON model inside every task (:77, :170) and moves pickled ITK
 Here the engines are built once per process; volume i+1 is uploaded on a side stream (pinned host buffer,
 PCIe Gen5: 94 MB in ~1.5 ms) while volume i computes, and results are copied back asynchronously.
 
+Round 6: the download of a volume's results is ISSUED BY THE DOWNLOAD WORKER after a host-side wait for the volume's compute -- queued behind the compute on
+the GPU, its barrier packet sat at the head of an in-order hardware queue for the whole volume and held back whatever stream shared the queue (_queue_d2h).
+
 Round 5: NO host memcpy on the launch thread.  A volume moves 94 MB pageable -> pinned before its upload and
 566 MB pinned -> pageable behind its download (five result tensors); on the thread that queues the kernels those copies
 (and the page faults of 566 MB of fresh memory per volume) kept the GPU waiting: 6.03 volumes/s streamed against 7.22 resident.
@@ -56,12 +59,11 @@ class CohortRunner:
         # parallel.CalibrationBoard of a multi-rank cohort (process_cohort): when a sidecar's fp16x3 calibration is dropped for not fitting the
         # data, ONE rank recalibrates and every rank takes that outcome -- polled before each volume is queued, never a blocking collective
         self.board = board
-        # What is left between the streamed and the resident rate (2-3 %): the runtime executes a D2H into pinned memory as a copy KERNEL on the
-        # compute units (`__amd_rocclr_copyBuffer` in the kernel trace of scripts/trace_cohort.py; the memory-copy trace holds no D2H entry), 7 ms
-        # per volume underneath the next volume's first kernels.  `high_priority_compute` queues the volumes' kernels on a high-priority stream
-        # of the runner's own so that the copy kernels yield -- measured 142.1 -> 136.2 ms per volume in one arrangement and 137 -> 142 in
-        # another (the ICON side stream's priority decides), so it is an experiment switch, NOT the default; and it takes the engines off the
-        # caller's stream: a consumer that uses the same pipeline between two results must then synchronise with the runner itself.
+        # `high_priority_compute` queues the volumes' kernels on a high-priority stream of the runner's own.  It dates from round 5, when the 2-4 ms between two
+        # streamed volumes were blamed on a copy kernel that the compute should pre-empt; round 6 found the real cause (a barrier packet parked in a shared
+        # hardware queue: _queue_d2h) and removed it, and found that the runtime's pinned D2H is an SDMA transfer outside the profiler (profiles/r06_cohort.md).
+        # The switch is kept for A/B only, NOT the default: it takes the engines off the caller's stream -- a consumer that uses the same pipeline between two
+        # results must then synchronise with the runner itself.
         dev_ = pipeline.unet.device
         self.compute_stream = torch.cuda.Stream(device=dev_, priority=torch.cuda.Stream.priority_range()[1]) if high_priority_compute else None
         self.copy_stream = torch.cuda.Stream(device=pipeline.unet.device)      # uploads (and the lazy normalisation of the next volume)
