@@ -12,6 +12,7 @@
 #include "unet_sres.h"
 #include "unet_sres2.h"
 #include "unet_wino.h"
+#include "unet_wino_f32.h"
 
 namespace oai {
 
@@ -33,6 +34,7 @@ struct Layer {
     std::vector<float> ws;              // per-cout weight scale of the fp16 panel (exact powers of two)
     int rel1 = 0;                       // exponent folded into the source-1 (skip) weights of the current fp16 panel: e(src0) - e(src1)
     size_t panel_f16_floats = 0;
+    float4* panel_wino_f32 = nullptr;   // fp32 panel of conv3_wino_f32 (pack_wino_f32_panel): the x axis in Winograd F(2,3) form, exact-fp32 path
     float4* panel_wino = nullptr;       // fp16 panel of conv3_wino_sres (pack_wino_panel): the x axis in Winograd F(2,3) form; packed with the same ws / rel1
     size_t panel_wino_floats = 0;
     float4* panel_wino16 = nullptr;     // the same weights laid out for the 16x16x32 taps of conv3_wino_sres<..., M16> (pack_wino16_panel; Cout % 128 == 0 only)
@@ -61,6 +63,7 @@ struct oai_unet {
     // headroom below 65504 and a floor of 2^-35 of the maximum.  Exact: powers of two fold into the epilogue affine and the panels.
     int act_exp[18] = {0};
     bool calibrated = false;
+    int opt_wino_f32 = 1;               // option "winograd_f32": the plain k3 layers of the exact-fp32 path run conv3_wino_f32 (x axis in Winograd F(2,3) form: 2/3 of the fp32 MFMAs)
     int opt_first_blocks = 24;          // option "first_blocks": workgroups per tile of the ec0 kernel conv3_first_sres_kernel (each walks the tile's voxel pairs with a grid stride, the next pair's gathers under the current pair's FMAs)
     int opt_up_nbw = 0;                 // option "up_nbw": column blocks per workgroup of the k2s2 up-conv kernel: 0 = as many as keep >= 16 workgroups per slot, 1 = one (rounds 1-5), n = at most n
     int opt_shared = 1;                 // option "shared_enc": ec0 -> ec1 computed ONCE over the reflect-padded volume + a 2-voxel shell per tile (oai_segment_tiles)
@@ -153,6 +156,35 @@ static std::vector<float> pack_conv3_panel(const std::vector<float>& wk, int C0,
                                 if (cl < Csrc && co < Cout) out[o] = wk[((size_t)t * Cin + cofs + cl) * Cout + co];
                             }
         }
+    return out;
+}
+
+// conv3_wino_f32 (unet_wino_f32.h): the x-transformed weights u0 = g0, u1 = (g0 + g1 + g2) / 2, u2 = (g0 - g1 + g2) / 2, u3 = g2 per (dz, dy, cin, cout), formed in double
+// and rounded to fp32 once; layout [cout block 64][frequency 4][chunk of 8 channels][tap (dz, dy) 9][cout half 2][lane 64][4]: lane (column = lane & 31, k half =
+// lane >> 5) holds channels 4 (lane >> 5) .. + 3 of cout 32 nr + column -- the B operands of four v_mfma_f32_32x32x2_f32 k-steps, like pack_conv3_panel.
+static std::vector<float> pack_wino_f32_panel(const std::vector<float>& wk, int C0, int C1, int Cout) {
+    constexpr int KC = 8;
+    const int Cin = C0 + C1;
+    const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+    std::vector<float> out(((size_t)ncb * 4 * (nch0 + nch1) * 9 * 2 + 2) * 64 * 4, 0.0f);     // + one tap of prefetch slack
+    size_t o = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int f = 0; f < 4; ++f)
+            for (int ch = 0; ch < nch0 + nch1; ++ch) {
+                const bool first = ch < nch0;
+                const int Csrc = first ? C0 : C1, cofs = first ? 0 : C0, cl0 = (first ? ch : ch - nch0) * KC;
+                for (int q = 0; q < 9; ++q)
+                    for (int nr = 0; nr < 2; ++nr)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int s = 0; s < 4; ++s, ++o) {
+                                const int cl = cl0 + 4 * (lane >> 5) + s;
+                                const int co = cb * 64 + nr * 32 + (lane & 31);
+                                if (cl >= Csrc || co >= Cout) continue;
+                                const double g0 = wk[((size_t)(q * 3 + 0) * Cin + cofs + cl) * Cout + co], g1 = wk[((size_t)(q * 3 + 1) * Cin + cofs + cl) * Cout + co],
+                                             g2 = wk[((size_t)(q * 3 + 2) * Cin + cofs + cl) * Cout + co];
+                                out[o] = (float)(f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5 : f == 2 ? (g0 - g1 + g2) * 0.5 : g2);
+                            }
+            }
     return out;
 }
 
@@ -873,6 +905,61 @@ static bool wino_pool_box(const Box& box, const int dims[3]) {
     return dims[0] % 4 == 0 && dims[1] % 8 == 0 && dims[2] % 8 == 0;      // main blocks only: no strips
 }
 
+// One launch of conv3_wino_f32 (unet_wino_f32.h) with blocks of 2 x TY x 2 NP over `box` (box.lo[2] even)
+template <int TY, int NP>
+static int launch_wino_f32_shape(const oai_unet* h, const Layer& L, ConvArgs a, const Box& box, int ntiles, hipStream_t st) {
+    for (int i = 0; i < 3; ++i) { a.lo[i] = box.lo[i]; a.hi[i] = box.hi[i]; }
+    if (box.hi[0] <= box.lo[0] || box.hi[1] <= box.lo[1] || box.hi[2] <= box.lo[2]) return OAI_OK;
+    a.wpanel = L.panel_wino_f32;
+    a.ncb = (a.Cout + 63) / 64;
+    a.nbz = cdiv(box.hi[0] - box.lo[0], 2); a.nby = cdiv(box.hi[1] - box.lo[1], TY); a.nbx = cdiv(box.hi[2] - box.lo[2], 2 * NP);
+    const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    oai_unet* hm = const_cast<oai_unet*>(h);
+    if (h->profile) {
+        if (hm->ev_used + 2 > hm->ev_pool.size()) {
+            hipEvent_t e0, e1;
+            OAI_CHECK_HIP(hipEventCreate(&e0));
+            OAI_CHECK_HIP(hipEventCreate(&e1));
+            hm->ev_pool.push_back(e0);
+            hm->ev_pool.push_back(e1);
+        }
+        OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
+    }
+    conv3_wino_f32<TY, NP><<<grid, 256, 0, st>>>(a);
+    OAI_CHECK_LAUNCH();
+    if (h->profile) {
+        OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));
+        hm->ev_used += 2;
+    }
+    return OAI_OK;
+}
+
+// The exact-fp32 path's k3 layers through conv3_wino_f32: main blocks of 2 x 8 x 8, a y strip of 2 x 4 x 16 blocks for a remainder of <= 4 rows, an x strip
+// of 2 x 16 x 4 blocks for a remainder of <= 4 columns (the cover of launch_conv3_wino).  The box starts at an even x: an output's arithmetic depends on the
+// parity of its x only -- not on which launch or block computes it.  A fused MaxPool3d(2) rides in the main blocks (the host passes it for whole-tile boxes only).
+static int launch_conv3_wino_f32(const oai_unet* h, const Layer& L, const ConvArgs& a, Box box, int ntiles, hipStream_t st) {
+    box.lo[2] &= ~1;
+    const int ry = box.hi[1] - box.lo[1], rx = box.hi[2] - box.lo[2];
+    int ny = ry / 8, nx = rx / 8, hr = ry - 8 * ny, wr = rx - 8 * nx;
+    if (ny == 0 || nx == 0 || a.pool_out) { ny = cdiv(ry, 8); nx = cdiv(rx, 8); hr = wr = 0; }
+    if (hr > 4) { ++ny; hr = 0; }
+    if (wr > 4) { ++nx; wr = 0; }
+    Box main = box, xs = box, ys = box;
+    main.hi[1] = hr ? box.lo[1] + 8 * ny : box.hi[1];
+    main.hi[2] = wr ? box.lo[2] + 8 * nx : box.hi[2];
+    if (int rc = launch_wino_f32_shape<8, 4>(h, L, a, main, ntiles, st)) return rc;
+    if (wr) {                                 // x strip: all y rows, the last wr columns
+        xs.lo[2] = main.hi[2];
+        if (int rc = launch_wino_f32_shape<16, 2>(h, L, a, xs, ntiles, st)) return rc;
+    }
+    if (hr) {                                 // y strip: the last hr rows, main columns only
+        ys.lo[1] = main.hi[1];
+        ys.hi[2] = main.hi[2];
+        if (int rc = launch_wino_f32_shape<4, 8>(h, L, a, ys, ntiles, st)) return rc;
+    }
+    return OAI_OK;
+}
+
 static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, const float* s1, float* out,
                         const int dims[3], const Box& box, int ntiles, hipStream_t st, const int* boxes = nullptr,
                         float* pool_out = nullptr, const ConvArgs* head = nullptr, const TileSource* first = nullptr,
@@ -880,6 +967,9 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     ConvArgs a;
     if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
+    if (h->precision == OAI_PREC_F32 && h->variant == 0 && h->opt_wino_f32 && L.panel_wino_f32 && !a.head_w && !a.first_w && !a.sc_boxes &&
+        (!a.pool_out || (wino_pool_box(box, dims) && dims[0] % 2 == 0)) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1))
+        return launch_conv3_wino_f32(h, L, a, box, ntiles, st);
     if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.sc_boxes &&
         (!a.pool_out || (a.Cout % 128 == 0 && a.relu && wino_pool_box(box, dims))) && a.Cout % 64 == 0 && (h->opt_wino & (a.Cout % 128 == 0 ? 1 : 2)) && (a.Cout % 128 == 0 || (a.C0 + 15) / 16 + (a.C1 + 15) / 16 >= 8) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1) && (size_t)dims[0] * dims[1] * dims[2] < (1u << 24))
         return launch_conv3_wino(h, L, a, box, ntiles, st);
@@ -1312,6 +1402,7 @@ int oai_unet_create(const oai_layer_params layers[OAI_UNET_NUM_LAYERS], float bn
         } else if (p.kind == 0 || p.kind == 1) {
             L.wk_host = canonical_k3(p);
             rc = upload(h, pack_conv3_panel(L.wk_host, L.c0, L.c1, p.cout, KC), &L.panel);
+            if (!rc && KC == 8) rc = upload(h, pack_wino_f32_panel(L.wk_host, L.c0, L.c1, p.cout), &L.panel_wino_f32);
         } else if (p.kind == 2) {
             L.wk_host.assign(p.weight_host, p.weight_host + (size_t)p.cin * p.cout * 8);     // [ci][co][2][2][2], for re-packing
             rc = upload(h, pack_up_panel(p), &L.panel);
@@ -1407,6 +1498,9 @@ int oai_unet_set_option(oai_unet* h, const char* name, int value) {
         // (A/B timing of the bookkeeping), so that the subnormal low-term loss cannot come back silently
         OAI_CHECK_ARG(value == 1 || h->calibrated, "oai_unet_set_option: census 0 needs a calibrated handle (activation exponents set)");
         h->opt_census = value;
+    } else if (!strcmp(name, "winograd_f32")) {        // NOT bit-preserving: the exact-fp32 path's plain k3 layers in Winograd F(2,3) form along x
+        OAI_CHECK_ARG(value == 0 || value == 1, "oai_unet_set_option: winograd_f32 must be 0 or 1");
+        h->opt_wino_f32 = value;
     } else if (!strcmp(name, "first_blocks")) {        // bit-preserving: workgroups per tile of the ec0 kernel (grid stride over the tile's voxel pairs)
         OAI_CHECK_ARG(value >= 1 && value <= 4096, "oai_unet_set_option: first_blocks must be in [1, 4096]");
         h->opt_first_blocks = value;

@@ -1,0 +1,233 @@
+// conv3_wino_f32: the exact-fp32 3x3x3 conv (precision OAI_PREC_F32: the reference-precision path, networks.py:43-64) with the x axis in Winograd
+// F(2,3) form -- two thirds of the fp32 MFMAs (round 6).
+//
+// conv3_igemm_f32 runs at 0.90 of the fp32 MFMA peak (v_mfma_f32_32x32x2_f32: 64 cycles per instruction and SIMD): only fewer MFMAs make that path
+// faster.  Along x an output pair (X, X + 1) of a k3 correlation needs the inputs d0..d3 = in[X - 1 .. X + 2] and, per (dz, dy, cin), six products;
+// in Winograd's minimal form four:
+//     t0 = d0 - d2   t1 = d1 + d2   t2 = d2 - d1   t3 = d1 - d3            (input transform, fp32)
+//     u0 = g0   u1 = (g0 + g1 + g2) / 2   u2 = (g0 - g1 + g2) / 2   u3 = g2 (weights: host, in double, rounded to fp32 once: pack_wino_f32_panel)
+//     m_f = sum over (dz, dy, cin) of t_f u_f                               (four GEMMs with K = 9 Cin instead of one with K = 27 Cin)
+//     out[X] = (m0 + m1) + m2       out[X + 1] = (m1 - m2) - m3
+// Products are exact fp32 x fp32 -> fp32 MFMA products as in conv3_igemm_f32, and the accumulation is the same TWO-LEVEL scheme: the 36 MFMAs of one
+// 8-channel chunk (9 taps x 4 k-steps) run into a fresh partial sum that is folded into the running sum by one add.  Emulated against float64
+// (scripts/study/winograd_x_f32_error.py: one layer, K = 576 ... 6 912): rms error 0.93-0.99 x the shipped two-level direct form's -- the shorter chains
+// pay for the transform's roundings.
+//
+// Workgroup = four waves = the four frequencies; block = 2 z x TY y x 2 NP x outputs (TY x NP = 32 pair rows = the M of the 32x32 MFMA tile per slice)
+// x 64 couts; wave f holds m_f for the whole block: 2 slices x 2 cout halves x 16 registers = 64 accumulators + 64 for the partial sums, the register
+// shape of conv3_igemm_f32.  Per chunk: [halo registers -> raw box (LDS)] [barrier] [transform raw -> T, one (hz, hy, pair, channel quad) unit per
+// thread] [barrier] [next chunk's halo loads issued] [9 taps: A fragments from T, weight fragments from L2 one tap ahead].  Epilogue: the four
+// frequencies of an output sit in four waves: every wave writes its 64 accumulators to LDS (64 KB, the raw box and T are dead), wave w then finalises
+// rows 8 w .. 8 w + 7 of every tile: output transform, scale / shift / ReLU, fp32 channels-last stores (32 consecutive couts = 128 bytes per lane row).
+// An output's bits depend on the parity of its x only (pairs start at even tile coordinates: the host aligns the launch box) -- not on blocks or batches.
+#pragma once
+#include "unet_kernels.h"
+
+namespace oai {
+
+template <int TY, int NP>
+__global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a) {
+    static_assert(TY * NP == 32, "32 pair rows per accumulator tile");
+    constexpr int KC = 8, MREP = 2, NREP = 2, TZ = MREP, HZ = TZ + 2, TX = 2 * NP, HY = TY + 2, HX = TX + 2;
+    constexpr int STRIDE = KC + 4;                    // floats per record (16-byte pad: bank spread, as conv3_igemm_f32)
+    constexpr int HVOX = HZ * HY * HX, Q = KC / 4, NSLOT = (HVOX * Q + 255) / 256;
+    constexpr int RAWF = HVOX * STRIDE;               // raw halo box [hz][hy][hx][STRIDE]
+    constexpr int TF = HZ * 4 * HY * NP * STRIDE;     // T [hz][f][hy][pair][STRIDE]
+    constexpr int XF = 4 * MREP * NREP * 16 * 64;     // epilogue exchange [f][m][n][r][lane]
+    constexpr int LDSF = RAWF + TF > XF ? RAWF + TF : XF;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    float* const raw = lds;
+    float* const T = lds + RAWF;
+
+    const int tid = threadIdx.x, lane = tid & 63, f = tid >> 6;
+    int id = blockIdx.x;
+    const int cb = id % a.ncb; id /= a.ncb;
+    const int bx = id % a.nbx; id /= a.nbx;
+    const int by = id % a.nby; id /= a.nby;
+    const int bz = id % a.nbz; id /= a.nbz;
+    const int tile = id;
+    const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * TY, ox0 = a.lo[2] + bx * TX;      // a.lo[2] is even (host)
+    int blo[3], bhi[3];
+    if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
+    if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + TY <= blo[1] || ox0 >= bhi[2] || ox0 + TX <= blo[2]) return;
+
+    f32x16 acc[MREP][NREP], part[MREP][NREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.0f; part[m][n][r] = 0.0f; }
+
+    const int row = lane & 31, half = lane >> 5;
+    const float* const a_ptr = T + ((f * HY + row / NP) * NP + row % NP) * STRIDE + 4 * half;      // this lane's record for tap (0, 0), slice 0
+    constexpr int SLICE = 4 * HY * NP * STRIDE, DYS = NP * STRIDE;
+
+    const int nch0 = (a.C0 + KC - 1) / KC, nch1 = (a.C1 + KC - 1) / KC, nchunks = nch0 + nch1;
+    // panel of pack_wino_f32_panel: [cb][f][chunk][tap 9][nr 2][lane] float4
+    const float4* wp = a.wpanel + (size_t)(cb * 4 + f) * nchunks * 9 * NREP * 64 + lane;
+    const size_t plane = (size_t)a.D * a.H * a.W;
+
+    float4 hreg[NSLOT];
+    auto halo_load = [&](int ch) __attribute__((always_inline)) {
+        const bool first = ch < nch0;
+        const float* src = first ? a.src0 : a.src1;
+        const int C = first ? a.C0 : a.C1;
+        const int c0 = (first ? ch : ch - nch0) * KC;
+        const float* sbase = src + (size_t)tile * plane * C + c0;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int slot = tid + i * 256;
+            const int hv = slot / Q, q = slot - hv * Q;
+            const int hx = hv % HX, t2 = hv / HX, hy = t2 % HY, hz = t2 / HY;
+            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < HVOX * Q && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 + 4 * q < C)
+                v = *reinterpret_cast<const float4*>(sbase + (((size_t)gz * a.H + gy) * a.W + gx) * C + 4 * q);
+            hreg[i] = v;
+        }
+    };
+    auto halo_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int slot = tid + i * 256;
+            const int hv = slot / Q, q = slot - hv * Q;
+            if (slot < HVOX * Q) *reinterpret_cast<float4*>(&raw[hv * STRIDE + 4 * q]) = hreg[i];
+        }
+    };
+    // raw -> T: one unit = the four frequencies of (hz, hy, pair p, channel quad q)
+    auto transform = [&]() __attribute__((always_inline)) {
+        constexpr int UNITS = HZ * HY * NP * Q;
+#pragma unroll
+        for (int ui = 0; ui < (UNITS + 255) / 256; ++ui) {
+            const int u = ui * 256 + tid;
+            if (u < UNITS) {
+                const int q = u % Q;
+                int t = u / Q;
+                const int p = t % NP; t /= NP;
+                const int hy = t % HY, hz = t / HY;
+                const float* r = raw + ((hz * HY + hy) * HX + 2 * p) * STRIDE + 4 * q;
+                const float4 d0 = *reinterpret_cast<const float4*>(r), d1 = *reinterpret_cast<const float4*>(r + STRIDE);
+                const float4 d2 = *reinterpret_cast<const float4*>(r + 2 * STRIDE), d3 = *reinterpret_cast<const float4*>(r + 3 * STRIDE);
+                float* tw = T + ((hz * 4 * HY + hy) * NP + p) * STRIDE + 4 * q;
+                constexpr int FS = HY * NP * STRIDE;
+                *reinterpret_cast<float4*>(tw) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+                *reinterpret_cast<float4*>(tw + FS) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+                *reinterpret_cast<float4*>(tw + 2 * FS) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+                *reinterpret_cast<float4*>(tw + 3 * FS) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+            }
+        }
+    };
+
+    float4 bcur[NREP], bnext[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) bcur[n] = wp[n * 64];
+    wp += NREP * 64;
+    halo_load(0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                                     // every wave is done reading T (and the raw box) of the previous chunk
+        halo_store();
+        __syncthreads();
+        transform();
+        __syncthreads();
+        if (ch + 1 < nchunks) halo_load(ch + 1);             // in flight behind this chunk's 144 MFMAs
+        float4 acur[MREP], anext[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) acur[m] = *reinterpret_cast<const float4*>(a_ptr + m * SLICE);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // the next tap's fragments are requested before this tap's 16 MFMAs: A from T (LDS), the weights from L2 (the panel has one tap of slack behind its end)
+            if (t + 1 < 9) {
+                const int dz = (t + 1) / 3, dy = (t + 1) % 3;
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) anext[m] = *reinterpret_cast<const float4*>(a_ptr + (m + dz) * SLICE + dy * DYS);
+            }
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
+            wp += NREP * 64;
+            __builtin_amdgcn_sched_barrier(0);
+            // (both z slices always: a block that straddles its box in z computes a slice it does not store -- a guard per MFMA costs more than it saves)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) {
+                    const float av = s == 0 ? acur[m].x : s == 1 ? acur[m].y : s == 2 ? acur[m].z : acur[m].w;
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n) {
+                        const float bv = s == 0 ? bcur[n].x : s == 1 ? bcur[n].y : s == 2 ? bcur[n].z : bcur[n].w;
+                        part[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, part[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) bcur[n] = bnext[n];
+            if (t + 1 < 9) {
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) acur[m] = anext[m];
+            }
+        }
+        // fold the chunk's partial sums into the running sums (one rounding per element and chunk)
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[m][n][r] += part[m][n][r]; part[m][n][r] = 0.0f; }
+    }
+
+    // ---- epilogue: exchange the frequencies through LDS, output transform, scale / shift / ReLU, stores
+    __syncthreads();
+    float* const XB = lds;
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) XB[(((f * MREP + m) * NREP + n) * 16 + r) * 64 + lane] = acc[m][n][r];
+    __syncthreads();
+    // wave w = f finalises registers r = 4 w + j of every tile: C/D row (r & 3) + 8 (r >> 2) + 4 half = j + 8 w + 4 half (a pair row), column = lane & 31.
+    // For TY x NP = 8 x 4 that is y = 2 w + half, pair j: the lane holds both z slices and both x of a 2 x 2 x 2 pooling window, its partner lane ^ 32 the other
+    // y row -- the fused MaxPool3d(2) (ec1 / ec3 / ec5, networks.py:113,117,122; the host passes pool_out only where the box is whole blocks) is one cross-lane max.
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = cb * 64 + n * 32 + row;
+        const bool cok = co < a.Cout;
+        float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
+        asm volatile("" : "+v"(sc), "+v"(sh));      // (the wait for the two loads lands here, once: see conv3_igemm_f32)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * f + j;
+            const int pr = j + 8 * f + 4 * half;
+            const int oy = oy0 + pr / NP, ox = ox0 + 2 * (pr % NP);
+            float pv = -3.0e38f;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int oz = oz0 + m;
+                const float* x = XB + ((m * NREP + n) * 16 + r) * 64 + lane;
+                constexpr int FSX = MREP * NREP * 16 * 64;
+                const float m0 = x[0], m1 = x[FSX], m2 = x[2 * FSX], m3 = x[3 * FSX];
+                float o0 = ((m0 + m1) + m2) * sc + sh, o1 = ((m1 - m2) - m3) * sc + sh;
+                if (a.relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); }
+                pv = fmaxf(pv, fmaxf(o0, o1));
+                if (cok && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1]) {
+                    float* dst = a.out + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co;
+                    if (ox >= blo[2] && ox < bhi[2]) dst[0] = o0;
+                    if (ox + 1 >= blo[2] && ox + 1 < bhi[2]) dst[a.Cout] = o1;
+                }
+            }
+            if constexpr (TY == 8 && NP == 4) {
+                if (a.pool_out) {                                          // (wave-uniform)
+                    pv = fmaxf(pv, __shfl_xor(pv, 32, 64));              // the window's other y row
+                    if (cok && half == 0) {
+                        const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
+                        a.pool_out[((((size_t)tile * Dp + oz0 / 2) * Hp + oy / 2) * Wp + ox / 2) * a.Cout + co] = pv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace oai
