@@ -31,9 +31,10 @@ sys.path.insert(0, ROOT)
 VOL_SHAPE = (160, 384, 384)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense 16-bit MFMA
+WINO_F32_EXECUTED = 2.0 / 3.0     # conv3_wino_f32: MFMAs executed per algorithmic MFMA (every k3 layer of the exact-fp32 path; ec0 has its own kernel)
 PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}
 SUSTAINED_16BIT_MFMA_TFLOPS = 1857.0   # scripts/micro/mfma_peak.hip on this chip: operands in registers, every CU (profiles/r01_ablation.md)
-KERNEL_OF = {"f32": "conv3_igemm_f32", "fp16x3": "conv3_wino_sres / conv3_igemm_sres (split-resident fp16x3; x axis of the plain layers in Winograd F(2,3) form)",
+KERNEL_OF = {"f32": "conv3_wino_f32 (exact fp32 products, x axis in Winograd F(2,3) form: 2/3 of the direct form's MFMAs; conv3_igemm_f32 with option winograd_f32=0)", "fp16x3": "conv3_wino_sres / conv3_igemm_sres (split-resident fp16x3; x axis of the plain layers in Winograd F(2,3) form)",
              "bf16x3": "conv3_igemm_bf16s (split 16-bit)", "bf16x6": "conv3_igemm_bf16s (split 16-bit)"}
 DTYPE_OF = {"f32": "f32", "bf16x6": "bf16x6 (fp32 operands split into 3 bf16 terms, 6 MFMA passes, fp32 accumulate)",
             "bf16x3": "bf16x3 (2 bf16 terms, 3 MFMA passes, fp32 accumulate)",
@@ -455,9 +456,12 @@ def main():
     unet_sd = make_unet_state_dict(0)
     icon_sd = make_icon_state_dict(0, last_scale=0.1)
     unet = UNetEngine(unet_sd, precision=args.precision)
+    wino_f32 = True                                                       # the library's default (option "winograd_f32")
     for opt in args.option:
         name, _, value = opt.partition("=")
         unet.set_option(name, int(value))
+        if name == "winograd_f32":
+            wino_f32 = bool(int(value))
     icon = IconEngine(icon_sd)
     atlas = Image(make_volume(1000, VOL_SHAPE), [0.36, 0.36, 0.7], [0.0, 0.0, 0.0])
     pipe = VolumePipeline(unet, icon, atlas, batch=args.batch or None)
@@ -590,9 +594,12 @@ def main():
                     "traffic_source": (TRAFFIC_FILE.get(prec, "none") + " (rocprofv3 --pmc, separate passes of this round's library at this launch size; "
                                        "NOT measured in this run)") if traffic_of(prec) is not None else None,
                     "achieved_frame_aware": ach_fa, "frac_frame_aware": ach_fa / peak,
-                    "mfma_passes_per_product": PASSES[prec], "executed_frac": ach_fa * PASSES[prec] / peak,
+                    "mfma_passes_per_product": PASSES[prec],
+                    "executed_frac": ach_fa * (WINO_F32_EXECUTED if prec == "f32" and wino_f32 else PASSES[prec]) / peak,
                     "executed_frac_of_sustained_issue_rate": None if prec == "f32" else ach_fa * PASSES[prec] / SUSTAINED_16BIT_MFMA_TFLOPS,
-                    "executed_note": None if prec == "f32" else
+                    "executed_note": ("every 3x3x3 layer of the exact-fp32 path runs conv3_wino_f32: four GEMMs with K = 9 Cin instead of one with K = 27 Cin = 2/3 of the "
+                                      "algorithmic MFMAs (unet_wino_f32.h); `frac` = algorithmic FLOP / time / peak can therefore exceed 1, executed_frac = frame-aware "
+                                      "algorithmic x 2/3 / peak is the matrix pipe's load" if wino_f32 else None) if prec == "f32" else
                     "executed_frac counts 3 MFMA passes per ALGORITHMIC product; the k3 layers without a fused ec0 / head (ec3-ec7 dc8 dc7 dc5 dc4 dc2, 78 % of the "
                     "3x3x3 algorithmic FLOP) run the x axis in Winograd F(2,3) form and execute 2/3 of that (unet_wino.h, profiles/r03_winograd.md, r04_wino_stream.md): for them "
                     "it overstates the matrix pipe's load, `frac` (algorithmic FLOP / time / peak) is the contract figure",

@@ -246,9 +246,11 @@ int oai_unet_set_act_exponents(oai_unet* h, const int e[OAI_UNET_NUM_LAYERS]);
  *   "persistent" 0|1 (0) bit-preserving (round 5): the 64-cout Winograd layer (dc2) with ONE persistent workgroup per CU that pulls blocks from per-XCD counters
  *                       (a small plan kernel in front of every launch) while its staging waves run one block ahead.  Built for VERDICT r4 #1 (b) / (d); measured
  *                       +-0 ... +0.8 % per pass (profiles/r05_persistent.md): not the default
- *   "winograd_f32" 0|1 (1) NOT bit-preserving (round 6): OAI_PREC_F32's plain k3 layers (no fused pool: ec2 ec4 ec6 ec7 dc8 dc7 dc5 dc4 dc2 dc1, 86 % of the 3x3x3 FLOP)
- *                       run conv3_wino_f32 (unet_wino_f32.h): the x axis in Winograd F(2,3) form, exact fp32 products, the same two-level accumulation = 2/3 of the
- *                       fp32 MFMAs; rms error against float64 0.93-0.99 x the direct form's (scripts/study/winograd_x_f32_error.py).  "winograd_layers" applies
+ *   "winograd_f32" 0|1 (1) NOT bit-preserving (round 6): every k3 layer of OAI_PREC_F32 (ec1 ... dc1; ec1 / ec3 / ec5 with their MaxPool3d fused where the launch is a
+ *                       whole tile) runs conv3_wino_f32 (unet_wino_f32.h): the x axis in Winograd F(2,3) form, exact fp32 products, the direct kernel's two-level
+ *                       accumulation = 2/3 of the fp32 MFMAs (pass 590 -> 445 ms), and 0.66-0.70 x the reference's own fp32 distance from its float64 run where the
+ *                       direct form (0) sits at 0.80-0.83 (profiles/r06_wino_f32.md).  A voxel's bits depend on the parity of its x, not on batches, launch boxes or
+ *                       strips.  "winograd_layers" applies
  *   "first_blocks" 1..4096 (24) bit-preserving (round 6): workgroups per tile of the ec0 kernel (networks.py:43 where it is not fused into ec1's staging: the 3-voxel
  *                       shell of every tile, the fp16x3 path without fuse_first); each walks the tile's voxel pairs with a grid stride, the next pair's 36 inputs
  *                       gathered under the current pair's FMAs (2.17 -> 1.38 ms per 160 tiles)

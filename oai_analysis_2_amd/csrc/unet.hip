@@ -166,7 +166,7 @@ static std::vector<float> pack_wino_f32_panel(const std::vector<float>& wk, int 
     constexpr int KC = 8;
     const int Cin = C0 + C1;
     const int ncb = (Cout + 63) / 64, nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
-    std::vector<float> out(((size_t)ncb * 4 * (nch0 + nch1) * 9 * 2 + 2) * 64 * 4, 0.0f);     // + one tap of prefetch slack
+    std::vector<float> out(((size_t)ncb * 4 * (nch0 + nch1) * 9 * 2 + 6) * 64 * 4, 0.0f);     // + three taps of prefetch slack
     size_t o = 0;
     for (int cb = 0; cb < ncb; ++cb)
         for (int f = 0; f < 4; ++f)
@@ -925,7 +925,7 @@ static int launch_wino_f32_shape(const oai_unet* h, const Layer& L, ConvArgs a, 
         }
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used], st));
     }
-    conv3_wino_f32<TY, NP><<<grid, 256, 0, st>>>(a);
+    conv3_wino_f32<TY, NP><<<grid, 256, 0, st>>>(a, reinterpret_cast<const float*>(h->zero_rec));
     OAI_CHECK_LAUNCH();
     if (h->profile) {
         OAI_CHECK_HIP(hipEventRecord(hm->ev_pool[hm->ev_used + 1], st));

@@ -25,19 +25,21 @@
 
 namespace oai {
 
-template <int TY, int NP>
-__global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a) {
+// EXP: timing probes of scripts/micro/wino_f32_ablate.hip (1: no fold, 2: no weight loads in the loop, 4: no input loads / transform, 8: no barrier per
+// chunk, 16: no A reads per tap, 32: the weight loads of every tap read the same address, 64: the input loads all read zero16 -- every one of them computes garbage); the library instantiates EXP = 0 only.
+template <int TY, int NP, int EXP = 0>
+__global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const float* __restrict__ zero16) {
     static_assert(TY * NP == 32, "32 pair rows per accumulator tile");
-    constexpr int KC = 8, MREP = 2, NREP = 2, TZ = MREP, HZ = TZ + 2, TX = 2 * NP, HY = TY + 2, HX = TX + 2;
+    constexpr int KC = 8, MREP = 2, NREP = 2, TZ = MREP, HZ = TZ + 2, TX = 2 * NP, HY = TY + 2;
     constexpr int STRIDE = KC + 4;                    // floats per record (16-byte pad: bank spread, as conv3_igemm_f32)
-    constexpr int HVOX = HZ * HY * HX, Q = KC / 4, NSLOT = (HVOX * Q + 255) / 256;
-    constexpr int RAWF = HVOX * STRIDE;               // raw halo box [hz][hy][hx][STRIDE]
-    constexpr int TF = HZ * 4 * HY * NP * STRIDE;     // T [hz][f][hy][pair][STRIDE]
+    constexpr int Q = KC / 4;
+    constexpr int UNITS = HZ * HY * NP * Q;           // one unit = (hz, hy, pair p, channel quad q): four inputs along x -> four frequencies
+    constexpr int NU = (UNITS + 255) / 256;
+    constexpr int FS = HY * NP * STRIDE;              // one frequency plane of a slice
+    constexpr int TF = HZ * 4 * FS;                   // T [hz][f][hy][pair][STRIDE], two of them (this chunk's and the next one's)
     constexpr int XF = 4 * MREP * NREP * 16 * 64;     // epilogue exchange [f][m][n][r][lane]
-    constexpr int LDSF = RAWF + TF > XF ? RAWF + TF : XF;
+    constexpr int LDSF = 2 * TF > XF ? 2 * TF : XF;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
-    float* const raw = lds;
-    float* const T = lds + RAWF;
 
     const int tid = threadIdx.x, lane = tid & 63, f = tid >> 6;
     int id = blockIdx.x;
@@ -60,92 +62,104 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) { acc[m][n][r] = 0.0f; part[m][n][r] = 0.0f; }
 
     const int row = lane & 31, half = lane >> 5;
-    const float* const a_ptr = T + ((f * HY + row / NP) * NP + row % NP) * STRIDE + 4 * half;      // this lane's record for tap (0, 0), slice 0
-    constexpr int SLICE = 4 * HY * NP * STRIDE, DYS = NP * STRIDE;
+    const int a_off = ((f * HY + row / NP) * NP + row % NP) * STRIDE + 4 * half;      // this lane's record for tap (0, 0), slice 0
+    constexpr int SLICE = 4 * FS, DYS = NP * STRIDE;
 
     const int nch0 = (a.C0 + KC - 1) / KC, nch1 = (a.C1 + KC - 1) / KC, nchunks = nch0 + nch1;
     // panel of pack_wino_f32_panel: [cb][f][chunk][tap 9][nr 2][lane] float4
     const float4* wp = a.wpanel + (size_t)(cb * 4 + f) * nchunks * 9 * NREP * 64 + lane;
     const size_t plane = (size_t)a.D * a.H * a.W;
 
-    float4 hreg[NSLOT];
-    auto halo_load = [&](int ch) __attribute__((always_inline)) {
+    // this thread's units: the voxel of d0, which of d0..d3 exist (bits 0..3; zero padding outside the image), the unit's place in T
+    int vox[NU], tw_off[NU], q4[NU];
+    unsigned okm[NU];
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui) {
+        const int u = ui * 256 + tid;
+        const int q = u % Q;
+        int t = u / Q;
+        const int p = t % NP; t /= NP;
+        const int hy = t % HY, hz = t / HY;
+        const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + 2 * p;
+        const bool rok = u < UNITS && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H;
+        unsigned mk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk |= (rok && (unsigned)(gx + k) < (unsigned)a.W) ? 1u << k : 0u;
+        okm[ui] = mk;
+        vox[ui] = (gz * a.H + gy) * a.W + gx;
+        q4[ui] = 4 * q;
+        tw_off[ui] = u < UNITS ? ((hz * 4 * HY + hy) * NP + p) * STRIDE + 4 * q : -1;
+    }
+
+    // Every thread issues the same NUMBER of loads whatever its units are (a missing unit, a voxel outside the image and the chunk behind the last one read
+    // the 16 zero bytes `zero16`): with loads under a branch the compiler can no longer count them and turns the weights' counted waits into full ones.
+    float4 hreg[NU][4];
+    auto unit_load = [&](int ch, bool real) __attribute__((always_inline)) {
         const bool first = ch < nch0;
         const float* src = first ? a.src0 : a.src1;
         const int C = first ? a.C0 : a.C1;
         const int c0 = (first ? ch : ch - nch0) * KC;
         const float* sbase = src + (size_t)tile * plane * C + c0;
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int slot = tid + i * 256;
-            const int hv = slot / Q, q = slot - hv * Q;
-            const int hx = hv % HX, t2 = hv / HX, hy = t2 % HY, hz = t2 / HY;
-            const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (slot < HVOX * Q && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 + 4 * q < C)
-                v = *reinterpret_cast<const float4*>(sbase + (((size_t)gz * a.H + gy) * a.W + gx) * C + 4 * q);
-            hreg[i] = v;
-        }
-    };
-    auto halo_store = [&]() __attribute__((always_inline)) {
+        for (int ui = 0; ui < NU; ++ui) {
+            const float* rp = sbase + (ptrdiff_t)vox[ui] * C + q4[ui];
+            const bool cok = real && c0 + q4[ui] < C;
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int slot = tid + i * 256;
-            const int hv = slot / Q, q = slot - hv * Q;
-            if (slot < HVOX * Q) *reinterpret_cast<float4*>(&raw[hv * STRIDE + 4 * q]) = hreg[i];
-        }
-    };
-    // raw -> T: one unit = the four frequencies of (hz, hy, pair p, channel quad q)
-    auto transform = [&]() __attribute__((always_inline)) {
-        constexpr int UNITS = HZ * HY * NP * Q;
-#pragma unroll
-        for (int ui = 0; ui < (UNITS + 255) / 256; ++ui) {
-            const int u = ui * 256 + tid;
-            if (u < UNITS) {
-                const int q = u % Q;
-                int t = u / Q;
-                const int p = t % NP; t /= NP;
-                const int hy = t % HY, hz = t / HY;
-                const float* r = raw + ((hz * HY + hy) * HX + 2 * p) * STRIDE + 4 * q;
-                const float4 d0 = *reinterpret_cast<const float4*>(r), d1 = *reinterpret_cast<const float4*>(r + STRIDE);
-                const float4 d2 = *reinterpret_cast<const float4*>(r + 2 * STRIDE), d3 = *reinterpret_cast<const float4*>(r + 3 * STRIDE);
-                float* tw = T + ((hz * 4 * HY + hy) * NP + p) * STRIDE + 4 * q;
-                constexpr int FS = HY * NP * STRIDE;
-                *reinterpret_cast<float4*>(tw) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-                *reinterpret_cast<float4*>(tw + FS) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-                *reinterpret_cast<float4*>(tw + 2 * FS) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-                *reinterpret_cast<float4*>(tw + 3 * FS) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+            for (int k = 0; k < 4; ++k) {
+                const float* p = (cok && ((okm[ui] >> k) & 1)) ? rp + (ptrdiff_t)k * C : zero16;
+                hreg[ui][k] = *reinterpret_cast<const float4*>(p);
             }
         }
     };
+    // frequency fq of unit ui -> Tb:   t0 = d0 - d2   t1 = d1 + d2   t2 = d2 - d1   t3 = d1 - d3
+    auto unit_piece = [&](float* Tb, int ui, int fq) __attribute__((always_inline)) {
+        if (tw_off[ui] >= 0) {
+            const float4 x = fq == 0 ? hreg[ui][0] : fq == 2 ? hreg[ui][2] : hreg[ui][1];
+            const float4 y = fq == 1 ? hreg[ui][2] : fq == 2 ? hreg[ui][1] : fq == 3 ? hreg[ui][3] : hreg[ui][2];
+            const float4 v = fq == 1 ? make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w) : make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+            *reinterpret_cast<float4*>(Tb + tw_off[ui] + fq * FS) = v;
+        }
+    };
 
-    float4 bcur[NREP], bnext[NREP];
+    // weight fragments: a ring of three taps, requested two taps ahead (L2 latency is longer than one tap's 16 MFMAs); 9 taps per chunk = 3 turns of the ring
+    float4 bq[3][NREP];
 #pragma unroll
-    for (int n = 0; n < NREP; ++n) bcur[n] = wp[n * 64];
-    wp += NREP * 64;
-    halo_load(0);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) bq[i][n] = wp[(i * NREP + n) * 64];
+    wp += 2 * NREP * 64;
+    unit_load(0, true);
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui)
+#pragma unroll
+        for (int fq = 0; fq < 4; ++fq) unit_piece(lds, ui, fq);
+    __syncthreads();
 
+    // One barrier per chunk: the next chunk's inputs are requested at the head of this chunk's taps (straight from global memory: every unit reads its own
+    // four voxels -- no raw staging box, the 2 x overlap of neighbouring pairs comes out of L1 / L2), transformed BETWEEN the MFMAs of tap kTapX into the
+    // other T buffer (two MFMAs, then the four VALU ops and the one LDS write of one frequency of one unit: the transform rides in the MFMAs' shadow).
+    constexpr int kTapX = 5;
+    static_assert(NU * 4 <= 8, "the pieces of a thread's units fit between the MFMA pairs of one tap");
     for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();                                     // every wave is done reading T (and the raw box) of the previous chunk
-        halo_store();
-        __syncthreads();
-        transform();
-        __syncthreads();
-        if (ch + 1 < nchunks) halo_load(ch + 1);             // in flight behind this chunk's 144 MFMAs
+        const float* const Tc = lds + (ch & 1) * TF + a_off;
+        float* const Tn = lds + ((ch + 1) & 1) * TF;
+        const bool more = ch + 1 < nchunks;
         float4 acur[MREP], anext[MREP];
 #pragma unroll
-        for (int m = 0; m < MREP; ++m) acur[m] = *reinterpret_cast<const float4*>(a_ptr + m * SLICE);
+        for (int m = 0; m < MREP; ++m) acur[m] = *reinterpret_cast<const float4*>(Tc + m * SLICE);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // the next tap's fragments are requested before this tap's 16 MFMAs: A from T (LDS), the weights from L2 (the panel has one tap of slack behind its end)
+            // the next tap's fragments are requested before this tap's 16 MFMAs: A from T (LDS), the weights from L2 two taps ahead (the panel has slack behind its end)
             if (t + 1 < 9) {
                 const int dz = (t + 1) / 3, dy = (t + 1) % 3;
 #pragma unroll
-                for (int m = 0; m < MREP; ++m) anext[m] = *reinterpret_cast<const float4*>(a_ptr + (m + dz) * SLICE + dy * DYS);
+                for (int m = 0; m < MREP; ++m) anext[m] = (EXP & 16) ? acur[m] : *reinterpret_cast<const float4*>(Tc + (m + dz) * SLICE + dy * DYS);
             }
 #pragma unroll
-            for (int n = 0; n < NREP; ++n) bnext[n] = wp[n * 64];
-            wp += NREP * 64;
+            for (int n = 0; n < NREP; ++n) bq[(t + 2) % 3][n] = (EXP & 2) ? bq[t % 3][n] : wp[n * 64];
+            if (!(EXP & 32)) wp += NREP * 64;
+            // the next chunk's inputs: requested BEHIND tap 2's weights -- vmcnt counts in order, the first wait that covers them is tap 3's
+            if (t == 0 && !(EXP & 4)) unit_load(more ? ch + 1 : ch, more && !(EXP & 64));
             __builtin_amdgcn_sched_barrier(0);
             // (both z slices always: a block that straddles its box in z computes a slice it does not store -- a guard per MFMA costs more than it saves)
 #pragma unroll
@@ -155,14 +169,19 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a) {
                     const float av = s == 0 ? acur[m].x : s == 1 ? acur[m].y : s == 2 ? acur[m].z : acur[m].w;
 #pragma unroll
                     for (int n = 0; n < NREP; ++n) {
-                        const float bv = s == 0 ? bcur[n].x : s == 1 ? bcur[n].y : s == 2 ? bcur[n].z : bcur[n].w;
+                        const float4 b4 = bq[t % 3][n];
+                        const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
                         part[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, part[m][n], 0, 0, 0);
+                    }
+                    if (t == kTapX) {
+                        const int piece = s * MREP + m;                       // 0..7
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more && piece < NU * 4 && !(EXP & 4)) unit_piece(Tn, piece / 4, piece % 4);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < NREP; ++n) bcur[n] = bnext[n];
             if (t + 1 < 9) {
 #pragma unroll
                 for (int m = 0; m < MREP; ++m) acur[m] = anext[m];
@@ -174,7 +193,11 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < NREP; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[m][n][r] += part[m][n][r]; part[m][n][r] = 0.0f; }
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (EXP & 1) { if (ch + 1 == nchunks) acc[m][n][r] = part[m][n][r]; }
+                    else { acc[m][n][r] += part[m][n][r]; part[m][n][r] = 0.0f; }
+                }
+        if constexpr (!(EXP & 8)) __syncthreads();           // T[next] is written, T[this] is read by every wave
     }
 
     // ---- epilogue: exchange the frequencies through LDS, output transform, scale / shift / ReLU, stores

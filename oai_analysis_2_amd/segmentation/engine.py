@@ -231,7 +231,8 @@ class UNetEngine:
         "sres", "sres_mrep", "sres_ring", "xcd_group", "fuse_first", "b_lds", "wide", "shared_enc", "dead_stores", "census", "up_nbw", "first_blocks".
         NOT bit-preserving: "winograd" (bit mask, default 19: the x axis of ten layers in Winograd F(2,3) form, bit 4 = 16x16x32 tap pairs -- other rounding,
         same parity gates; 0 = the direct form everywhere), "winograd_layers" (which layers), "m16" (default 1: the direct kernel of the layers with
-        Cout % 128 != 0 on 16x16x32 tap pairs), "m16_layers" and "persistent" (default 0: dc2 with persistent workgroups, bit-identical, not faster)."""
+        Cout % 128 != 0 on 16x16x32 tap pairs), "m16_layers" and "persistent" (default 0: dc2 with persistent workgroups, bit-identical, not faster); of the exact-fp32 path: "winograd_f32" (default 1: its
+        k3 layers in x-axis Winograd form on exact fp32 products -- 2/3 of the fp32 MFMAs and closer to float64 than the direct form 0)."""
         _lib.check(self.lib.oai_unet_set_option(self._h, name.encode(), int(value)), "oai_unet_set_option")
         if name == "sres":
             # sres 0 = the superseded kernels that keep fp32 activations in memory and split them while staging: no range census, no

@@ -26,14 +26,15 @@ def load(path, name):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
 def traffic_f32():
-    """exact-fp32 leg: bytes per conv3_igemm_f32 launch of the warm 32-tile pass (no ec0 fusion there: a pass starts at conv3_first_kernel)"""
+    """exact-fp32 leg: bytes per k3 launch (conv3_wino_f32, round 6; conv3_igemm_f32 before / with winograd_f32=0) of the warm pass (no ec0 fusion there: a pass starts at conv3_first_kernel)"""
     f = load(find("fetch32", "counter_collection.csv"), "FETCH_SIZE"); w = load(find("write32", "counter_collection.csv"), "WRITE_SIZE")
     cut = lambda rows: rows[max(k for k, r in enumerate(rows) if "conv3_first" in r["Kernel_Name"]):]
     f, w = cut(f), cut(w)
-    tf = sum(2 * float(a["Counter_Value"]) * 1024 for a in f if "conv3_igemm_f32" in a["Kernel_Name"])
-    tw = sum(float(a["Counter_Value"]) * 1024 for a in w if "conv3_igemm_f32" in a["Kernel_Name"])
-    n = sum(1 for a in f if "conv3_igemm_f32" in a["Kernel_Name"])
-    js = {"kernel": "conv3_igemm_f32 (all tile shapes)", "bytes_per_launch": (tf + tw) / max(n, 1), "tiles_per_pass": int(os.environ.get("TILES", "160")),
+    k3 = lambda a: "conv3_igemm_f32" in a["Kernel_Name"] or "conv3_wino_f32" in a["Kernel_Name"]
+    tf = sum(2 * float(a["Counter_Value"]) * 1024 for a in f if k3(a))
+    tw = sum(float(a["Counter_Value"]) * 1024 for a in w if k3(a))
+    n = sum(1 for a in f if k3(a))
+    js = {"kernel": "conv3_wino_f32 / conv3_igemm_f32 (all block shapes; main launches and strips count as launches, as in bench.py)", "bytes_per_launch": (tf + tw) / max(n, 1), "tiles_per_pass": int(os.environ.get("TILES", "160")),
           "fetch_x2_bytes_per_pass": tf, "write_bytes_per_pass": tw, "launches_per_pass": n}
     json.dump(js, open(O + "/traffic_f32.json", "w"), indent=1)
     print(json.dumps(js))

@@ -2,7 +2,7 @@
 # SQ / GRBM counters of the segmentation kernels (own pass: counters + kernel-trace only) for each OPTIONS string: bash scripts/sq_pass.sh "wide=0" "wide=1"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/sq_pass; rm -rf $O; mkdir -p $O; cd $R
-export PREC=fp16x3
+export PREC=${PREC:-fp16x3}
 i=0
 for opt in "$@"; do
   export OPTIONS="$opt"

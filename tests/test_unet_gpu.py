@@ -340,3 +340,34 @@ def test_maps_do_not_depend_on_batching_or_tile_ranges(wino):
         assert torch.equal(st(whole), ref), (b, e, batch)
     eng.set_option("shared_enc", 0)
     assert torch.equal(st(eng.segment_tiles(v, tile, ovl, None, 2, 5, crop)), ref)
+
+
+def test_exact_fp32_winograd_form_against_the_direct_form_and_across_batches():
+    """Round 6: the exact-fp32 path runs its k3 layers through conv3_wino_f32 (x axis in Winograd F(2,3) form, fp32 products, the direct kernel's
+    two-level accumulation; option "winograd_f32", default 1).  Same precision, other rounding points than the direct form (0): the logits agree
+    to fp32 noise; against float64 its error is the direct form's (tests/test_fullsize_gpu.py gates both against the reference).  And as on the
+    fp16x3 path a voxel's bits do not depend on the batch, the launch box or the strip that covers it (ragged volume: main blocks, both strip
+    shapes, border tiles with trimmed boxes, the fused MaxPool of ec1 / ec3 / ec5 in whole-tile launches)."""
+    from oai_analysis_2_amd.segmentation.engine import UNetEngine
+    tile, ovl, shape = (24, 40, 64), (6, 4, 8), (28, 66, 154)
+    crop = (ovl[0], ovl[2], ovl[1])
+    v = torch.from_numpy(make_volume(201, shape)).cuda()
+    eng = UNetEngine(make_unet_state_dict(seed=51, width_div=1), precision="f32")
+    st = lambda b: eng.stitch(b, shape, tile, ovl, crop)
+    ref = st(eng.segment_tiles(v, tile, ovl, None, 2, 6, crop))
+    for batch in (1, 5, 36):
+        assert torch.equal(st(eng.segment_tiles(v, tile, ovl, None, 2, batch, crop)), ref), batch
+    whole = eng.segment_tiles(v, tile, ovl, None, 2, 6, crop)
+    whole[5:19] = eng.segment_tiles(v, tile, ovl, (5, 19), 2, 7, crop)
+    assert torch.equal(st(whole), ref)
+    eng.set_option("winograd_f32", 0)
+    direct = st(eng.segment_tiles(v, tile, ovl, None, 2, 6, crop))
+    scale = float(direct.abs().max())
+    err = float((ref - direct).abs().max()) / scale
+    assert 0.0 < err < 2e-5, err                 # two fp32 evaluations of a 17-layer network (logits): different bits, fp32 noise apart
+    # whole-tile launches (no trimming: forward_tiles): the pooled levels come out of the fused epilogue on both paths
+    x = torch.from_numpy(np.stack([make_volume(202, tile), make_volume(203, tile)]))[:, None].cuda()
+    d = eng.forward_tiles(x)
+    eng.set_option("winograd_f32", 1)
+    w = eng.forward_tiles(x)
+    assert 0.0 < float((w - d).abs().max()) / float(d.abs().max()) < 2e-5
