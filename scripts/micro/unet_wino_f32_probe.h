@@ -1,4 +1,6 @@
-// conv3_wino_f32: the exact-fp32 3x3x3 conv (precision OAI_PREC_F32: the reference-precision path, networks.py:43-64) with the x axis in Winograd
+// PROBE COPY of oai_analysis_2_amd/csrc/unet_wino_f32.h (round 6, the version that shipped) with the EXP timing switches of scripts/micro/wino_f32_ablate.hip:
+// EXP != 0 computes garbage.  Not part of the library; kept out of the product source on purpose.
+// conv3_wino_f32_probe: the exact-fp32 3x3x3 conv (precision OAI_PREC_F32: the reference-precision path, networks.py:43-64) with the x axis in Winograd
 // F(2,3) form -- two thirds of the fp32 MFMAs (round 6).
 //
 // conv3_igemm_f32 runs at 0.90 of the fp32 MFMA peak (v_mfma_f32_32x32x2_f32: 64 cycles per instruction and SIMD): only fewer MFMAs make that path
@@ -21,12 +23,14 @@
 // rows 8 w .. 8 w + 7 of every tile: output transform, scale / shift / ReLU, fp32 channels-last stores (32 consecutive couts = 128 bytes per lane row).
 // An output's bits depend on the parity of its x only (pairs start at even tile coordinates: the host aligns the launch box) -- not on blocks or batches.
 #pragma once
-#include "unet_kernels.h"
+#include "../../oai_analysis_2_amd/csrc/unet_kernels.h"
 
 namespace oai {
 
-template <int TY, int NP>
-__global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const float* __restrict__ zero16) {
+// EXP: timing probes of scripts/micro/wino_f32_ablate.hip (1: no fold, 2: no weight loads in the loop, 4: no input loads / transform, 8: no barrier per
+// chunk, 16: no A reads per tap, 32: the weight loads of every tap read the same address, 64: the input loads all read zero16 -- every one of them computes garbage); the library instantiates EXP = 0 only.
+template <int TY, int NP, int EXP = 0>
+__global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a, const float* __restrict__ zero16) {
     static_assert(TY * NP == 32, "32 pair rows per accumulator tile");
     constexpr int KC = 8, MREP = 2, NREP = 2, TZ = MREP, HZ = TZ + 2, TX = 2 * NP, HY = TY + 2;
     constexpr int STRIDE = KC + 4;                    // floats per record (16-byte pad: bank spread, as conv3_igemm_f32)
@@ -151,13 +155,13 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
             if (t + 1 < 9) {
                 const int dz = (t + 1) / 3, dy = (t + 1) % 3;
 #pragma unroll
-                for (int m = 0; m < MREP; ++m) anext[m] = *reinterpret_cast<const float4*>(Tc + (m + dz) * SLICE + dy * DYS);
+                for (int m = 0; m < MREP; ++m) anext[m] = (EXP & 16) ? acur[m] : *reinterpret_cast<const float4*>(Tc + (m + dz) * SLICE + dy * DYS);
             }
 #pragma unroll
-            for (int n = 0; n < NREP; ++n) bq[(t + 2) % 3][n] = wp[n * 64];
-            wp += NREP * 64;
+            for (int n = 0; n < NREP; ++n) bq[(t + 2) % 3][n] = (EXP & 2) ? bq[t % 3][n] : wp[n * 64];
+            if (!(EXP & 32)) wp += NREP * 64;
             // the next chunk's inputs: requested BEHIND tap 2's weights -- vmcnt counts in order, the first wait that covers them is tap 3's
-            if (t == 0) unit_load(more ? ch + 1 : ch, more);
+            if (t == 0 && !(EXP & 4)) unit_load(more ? ch + 1 : ch, more && !(EXP & 64));
             __builtin_amdgcn_sched_barrier(0);
             // (both z slices always: a block that straddles its box in z computes a slice it does not store -- a guard per MFMA costs more than it saves)
 #pragma unroll
@@ -174,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
                     if (t == kTapX) {
                         const int piece = s * MREP + m;                       // 0..7
                         __builtin_amdgcn_sched_barrier(0);
-                        if (more && piece < NU * 4) unit_piece(Tn, piece / 4, piece % 4);
+                        if (more && piece < NU * 4 && !(EXP & 4)) unit_piece(Tn, piece / 4, piece % 4);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -191,8 +195,11 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
 #pragma unroll
             for (int n = 0; n < NREP; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[m][n][r] += part[m][n][r]; part[m][n][r] = 0.0f; }
-        __syncthreads();                                     // T[next] is written, T[this] is read by every wave
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (EXP & 1) { if (ch + 1 == nchunks) acc[m][n][r] = part[m][n][r]; }
+                    else { acc[m][n][r] += part[m][n][r]; part[m][n][r] = 0.0f; }
+                }
+        if constexpr (!(EXP & 8)) __syncthreads();           // T[next] is written, T[this] is read by every wave
     }
 
     // ---- epilogue: exchange the frequencies through LDS, output transform, scale / shift / ReLU, stores

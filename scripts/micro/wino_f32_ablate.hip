@@ -1,11 +1,12 @@
 // Where does conv3_wino_f32 (csrc/unet_wino_f32.h) lose its MFMA slots?  One layer shape (32 tiles of 32 x 128 x 128, Cin 64 -> Cout 64: 8 chunks), the
-// shipped kernel next to its EXP probes (each removes one ingredient and computes garbage), the direct kernel conv3_igemm_f32 on the same shape, and a
+// shipped kernel next to the EXP probes of its copy unet_wino_f32_probe.h (each removes one ingredient and computes garbage), the direct kernel conv3_igemm_f32 on the same shape, and a
 // register-only loop of the same MFMA (the sustained fp32 MFMA rate at this occupancy).  Build + run: scripts/micro/run_wino_f32_ablate.sh
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../oai_analysis_2_amd/csrc/unet_wino_f32.h"
+#include "../../oai_analysis_2_amd/csrc/unet_wino_f32.h"     // the shipped kernel
+#include "unet_wino_f32_probe.h"                            // its copy with the EXP switches
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -74,8 +75,9 @@ int main() {
     const unsigned gw = (unsigned)tiles * a.nbz * a.nby * a.nbx;
     const double mw = (double)gw * 4 * nch * 144;
     const ConvArgs aw = a;
-#define RUNW(E, label) report(label, time_ms([&] { conv3_wino_f32<8, 4, E><<<gw, 256>>>(aw, zero); }, 5), mw)
-    RUNW(0, "conv3_wino_f32 (shipped)");
+#define RUNW(E, label) report(label, time_ms([&] { conv3_wino_f32_probe<8, 4, E><<<gw, 256>>>(aw, zero); }, 5), mw)
+    report("conv3_wino_f32 (shipped)", time_ms([&] { conv3_wino_f32<8, 4><<<gw, 256>>>(aw, zero); }, 5), mw);
+    RUNW(0, "  probe copy, EXP 0");
     RUNW(1, "  EXP 1: no fold per chunk");
     RUNW(2, "  EXP 2: no weight loads in the tap loop");
     RUNW(4, "  EXP 4: no input loads, no transform");

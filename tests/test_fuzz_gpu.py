@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("script,env", [("fuzz_seg.py", {"SEED": "0", "CASES": "4", "SHARED_CASES": "4"}),
                                         ("fuzz_seg.py", {"SEED": "7", "CASES": "2", "SHARED_CASES": "4"}),
+                                        ("fuzz_seg.py", {"SEED": "3", "CASES": "4", "PRECISION": "f32"}),      # the exact-fp32 path (conv3_wino_f32): oracle parity + batch independence
                                         ("fuzz_reg.py", {})])
 def test_randomised_parity(script, env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script)], capture_output=True, text=True, timeout=1500, cwd=ROOT,
