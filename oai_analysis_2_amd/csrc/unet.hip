@@ -913,7 +913,12 @@ static int launch_wino_f32_shape(const oai_unet* h, const Layer& L, ConvArgs a, 
     a.wpanel = L.panel_wino_f32;
     a.ncb = (a.Cout + 63) / 64;
     a.nbz = cdiv(box.hi[0] - box.lo[0], 2); a.nby = cdiv(box.hi[1] - box.lo[1], TY); a.nbx = cdiv(box.hi[2] - box.lo[2], 2 * NP);
-    const unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    unsigned grid = (unsigned)((size_t)ntiles * a.nbz * a.nby * a.nbx * a.ncb);
+    if (h->xcd_group > 0) {                                // XCD-aware dealing of the logical block list (xcd_block_id), as the split-resident kernels
+        a.nblocks = (int)grid; a.xcd_group = h->xcd_group;
+        const unsigned q = 8u * (unsigned)h->xcd_group;
+        grid = (grid + q - 1) / q * q;
+    }
     oai_unet* hm = const_cast<oai_unet*>(h);
     if (h->profile) {
         if (hm->ev_used + 2 > hm->ev_pool.size()) {

@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
     const int tid = threadIdx.x, lane = tid & 63, f = tid >> 6;
-    int id = blockIdx.x;
+    int id = a.xcd_group ? xcd_block_id(a.nblocks, a.xcd_group) : (int)blockIdx.x;      // neighbours (and the cout blocks of one spatial block) on ONE XCD's L2
+    if (id < 0) return;
     const int cb = id % a.ncb; id /= a.ncb;
     const int bx = id % a.nbx; id /= a.nbx;
     const int by = id % a.nby; id /= a.nby;

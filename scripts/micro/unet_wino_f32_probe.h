@@ -27,7 +27,7 @@
 
 namespace oai {
 
-// EXP: timing probes of scripts/micro/wino_f32_ablate.hip (1: no fold, 2: no weight loads in the loop, 4: no input loads / transform, 8: no barrier per
+// EXP (128: the input loads fetch full 128-byte lines once per four chunks): timing probes of scripts/micro/wino_f32_ablate.hip (1: no fold, 2: no weight loads in the loop, 4: no input loads / transform, 8: no barrier per
 // chunk, 16: no A reads per tap, 32: the weight loads of every tap read the same address, 64: the input loads all read zero16 -- every one of them computes garbage); the library instantiates EXP = 0 only.
 template <int TY, int NP, int EXP = 0>
 __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a, const float* __restrict__ zero16) {
@@ -102,6 +102,23 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a,
         const int C = first ? a.C0 : a.C1;
         const int c0 = (first ? ch : ch - nch0) * KC;
         const float* sbase = src + (size_t)tile * plane * C + c0;
+        if constexpr ((EXP & 128) != 0) {
+            // EXP 128: what would FULL-LINE input fetches buy?  The halo of FOUR chunks (32 channels = one 128-byte line per voxel) is read once per four
+            // chunks, eight lanes per voxel: the same bytes out of HBM, a quarter of the L2 -> L1 line requests (13 loads per thread and four chunks instead of 32)
+            constexpr int HXp = TX + 2, HVOXp = HZ * HY * HXp;
+            const int phase = ch & 3, n0 = phase == 0 ? 0 : 8, n1 = phase == 0 ? 8 : phase == 1 ? 13 : 8;
+            const float* gbase = src + (size_t)tile * plane * C + (c0 & ~31);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int slot = tid + (n0 + i) * 256, hv = slot >> 3, piece = slot & 7;
+                const int hx = hv % HXp, t2 = hv / HXp, hy = t2 % HY, hz = t2 / HY;
+                const int gz = oz0 - 1 + hz, gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+                const bool ok = real && n0 + i < n1 && hv < HVOXp && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && (c0 & ~31) + 4 * piece < C;
+                const float* p = ok ? gbase + ((ptrdiff_t)(gz * a.H + gy) * a.W + gx) * C + 4 * piece : zero16;
+                hreg[i >> 2][i & 3] = *reinterpret_cast<const float4*>(p);
+            }
+            return;
+        }
 #pragma unroll
         for (int ui = 0; ui < NU; ++ui) {
             const float* rp = sbase + (ptrdiff_t)vox[ui] * C + q4[ui];

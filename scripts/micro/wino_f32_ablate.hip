@@ -86,6 +86,8 @@ int main() {
     RUNW(32, "  EXP 32: weight loads from one address (L1)");
     RUNW(64, "  EXP 64: input loads from one address (L1)");
     RUNW(96, "  EXP 32+64");
+    RUNW(128, "  EXP 128: full-line input fetches, once per 4 chunks");
+    RUNW(160, "  EXP 128+32");
     RUNW(6, "  EXP 2+4");
     RUNW(22, "  EXP 2+4+16");
     RUNW(30, "  EXP 2+4+8+16");
