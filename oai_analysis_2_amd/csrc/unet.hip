@@ -972,7 +972,7 @@ static int launch_conv3(const oai_unet* h, const Layer& L, const float* s0, cons
     ConvArgs a;
     if (int rc = fill_conv_args(h, L, s0, s1, out, dims, boxes, pool_out, head, first, store_boxes, sc, a)) return rc;
     if (h->variant == 1) return launch_conv3_shape<2, 16, 16, 2, 4, 1>(h, a, box, ntiles, st);
-    if (h->precision == OAI_PREC_F32 && h->variant == 0 && h->opt_wino_f32 && L.panel_wino_f32 && !a.head_w && !a.first_w && !a.sc_boxes &&
+    if (h->precision == OAI_PREC_F32 && h->variant == 0 && h->opt_wino_f32 && L.panel_wino_f32 && a.Cout % 4 == 0 && !a.head_w && !a.first_w && !a.sc_boxes &&
         (!a.pool_out || (wino_pool_box(box, dims) && dims[0] % 2 == 0)) && ((h->opt_wino_layers >> (int)(&L - h->L)) & 1))
         return launch_conv3_wino_f32(h, L, a, box, ntiles, st);
     if (h->sres && h->opt_wino && L.panel_wino && h->sres_mrep == 4 && !h->sres_ring && !h->b_lds && !a.first_w && !a.head_w && !a.sc_boxes &&

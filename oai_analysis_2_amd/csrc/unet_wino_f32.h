@@ -206,43 +206,55 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) XB[(((f * MREP + m) * NREP + n) * 16 + r) * 64 + lane] = acc[m][n][r];
     __syncthreads();
-    // wave w = f finalises registers r = 4 w + j of every tile: C/D row (r & 3) + 8 (r >> 2) + 4 half = j + 8 w + 4 half (a pair row), column = lane & 31.
-    // For TY x NP = 8 x 4 that is y = 2 w + half, pair j: the lane holds both z slices and both x of a 2 x 2 x 2 pooling window, its partner lane ^ 32 the other
-    // y row -- the fused MaxPool3d(2) (ec1 / ec3 / ec5, networks.py:113,117,122; the host passes pool_out only where the box is whole blocks) is one cross-lane max.
+    // Wave w = f finalises registers r = 4 w + j of every tile: C/D row (r & 3) + 8 (r >> 2) + 4 half = j + 8 w + 4 half (a pair row), column = cout.  A register row of
+    // the exchange buffer is [half 2][cout 32] floats, so a lane takes FOUR consecutive couts of one (j, half): lane = (j, half, cout quad) -- 16-byte LDS reads,
+    // 16-byte stores (eight store instructions per wave instead of 64; Cout % 4 == 0: host).  For TY x NP = 8 x 4 the pair row is y = 2 w + half, pair j: the lane holds
+    // both z slices and both x of a 2 x 2 x 2 pooling window, its partner lane ^ 8 the other y row -- the fused MaxPool3d(2) (ec1 / ec3 / ec5, networks.py:113,117,122;
+    // the host passes pool_out only where the box is whole blocks) is one cross-lane max.
+    const int cq = lane & 7, eh = (lane >> 3) & 1, ej = lane >> 4;
+    const int pr = ej + 8 * f + 4 * eh;
+    const int oy = oy0 + pr / NP, ox = ox0 + 2 * (pr % NP);
+    const bool yok = oy >= blo[1] && oy < bhi[1], x0ok = ox >= blo[2] && ox < bhi[2], x1ok = ox + 1 >= blo[2] && ox + 1 < bhi[2];
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
-        const int co = cb * 64 + n * 32 + row;
+        const int co = cb * 64 + n * 32 + 4 * cq;
         const bool cok = co < a.Cout;
-        float sc = cok ? a.scale[co] : 0.0f, sh = cok ? a.shift[co] : 0.0f;
-        asm volatile("" : "+v"(sc), "+v"(sh));      // (the wait for the two loads lands here, once: see conv3_igemm_f32)
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sc = cok ? *reinterpret_cast<const float4*>(a.scale + co) : zero4, sh = cok ? *reinterpret_cast<const float4*>(a.shift + co) : zero4;
+        asm volatile("" : "+v"(sc.x), "+v"(sc.y), "+v"(sc.z), "+v"(sc.w), "+v"(sh.x), "+v"(sh.y), "+v"(sh.z), "+v"(sh.w));      // (the wait for the loads lands here, once)
+        float4 pv = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 4 * f + j;
-            const int pr = j + 8 * f + 4 * half;
-            const int oy = oy0 + pr / NP, ox = ox0 + 2 * (pr % NP);
-            float pv = -3.0e38f;
-#pragma unroll
-            for (int m = 0; m < MREP; ++m) {
-                const int oz = oz0 + m;
-                const float* x = XB + ((m * NREP + n) * 16 + r) * 64 + lane;
-                constexpr int FSX = MREP * NREP * 16 * 64;
-                const float m0 = x[0], m1 = x[FSX], m2 = x[2 * FSX], m3 = x[3 * FSX];
-                float o0 = ((m0 + m1) + m2) * sc + sh, o1 = ((m1 - m2) - m3) * sc + sh;
-                if (a.relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); }
-                pv = fmaxf(pv, fmaxf(o0, o1));
-                if (cok && oz >= blo[0] && oz < bhi[0] && oy >= blo[1] && oy < bhi[1]) {
-                    float* dst = a.out + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co;
-                    if (ox >= blo[2] && ox < bhi[2]) dst[0] = o0;
-                    if (ox + 1 >= blo[2] && ox + 1 < bhi[2]) dst[a.Cout] = o1;
-                }
+        for (int m = 0; m < MREP; ++m) {
+            const int oz = oz0 + m;
+            const float* x = XB + ((m * NREP + n) * 16 + 4 * f + ej) * 64 + eh * 32 + 4 * cq;
+            constexpr int FSX = MREP * NREP * 16 * 64;
+            const float4 m0 = *reinterpret_cast<const float4*>(x), m1 = *reinterpret_cast<const float4*>(x + FSX);
+            const float4 m2 = *reinterpret_cast<const float4*>(x + 2 * FSX), m3 = *reinterpret_cast<const float4*>(x + 3 * FSX);
+            float4 o0, o1;
+            o0.x = ((m0.x + m1.x) + m2.x) * sc.x + sh.x; o1.x = ((m1.x - m2.x) - m3.x) * sc.x + sh.x;
+            o0.y = ((m0.y + m1.y) + m2.y) * sc.y + sh.y; o1.y = ((m1.y - m2.y) - m3.y) * sc.y + sh.y;
+            o0.z = ((m0.z + m1.z) + m2.z) * sc.z + sh.z; o1.z = ((m1.z - m2.z) - m3.z) * sc.z + sh.z;
+            o0.w = ((m0.w + m1.w) + m2.w) * sc.w + sh.w; o1.w = ((m1.w - m2.w) - m3.w) * sc.w + sh.w;
+            if (a.relu) {
+                o0 = make_float4(fmaxf(o0.x, 0.f), fmaxf(o0.y, 0.f), fmaxf(o0.z, 0.f), fmaxf(o0.w, 0.f));
+                o1 = make_float4(fmaxf(o1.x, 0.f), fmaxf(o1.y, 0.f), fmaxf(o1.z, 0.f), fmaxf(o1.w, 0.f));
             }
-            if constexpr (TY == 8 && NP == 4) {
-                if (a.pool_out) {                                          // (wave-uniform)
-                    pv = fmaxf(pv, __shfl_xor(pv, 32, 64));              // the window's other y row
-                    if (cok && half == 0) {
-                        const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
-                        a.pool_out[((((size_t)tile * Dp + oz0 / 2) * Hp + oy / 2) * Wp + ox / 2) * a.Cout + co] = pv;
-                    }
+            pv = make_float4(fmaxf(pv.x, fmaxf(o0.x, o1.x)), fmaxf(pv.y, fmaxf(o0.y, o1.y)), fmaxf(pv.z, fmaxf(o0.z, o1.z)), fmaxf(pv.w, fmaxf(o0.w, o1.w)));
+            if (cok && yok && oz >= blo[0] && oz < bhi[0]) {
+                float* dst = a.out + ((size_t)tile * plane + ((size_t)oz * a.H + oy) * a.W + ox) * a.Cout + co;
+                if (x0ok) *reinterpret_cast<float4*>(dst) = o0;
+                if (x1ok) *reinterpret_cast<float4*>(dst + a.Cout) = o1;
+            }
+        }
+        if constexpr (TY == 8 && NP == 4) {
+            if (a.pool_out) {                                          // (wave-uniform)
+                pv.x = fmaxf(pv.x, __shfl_xor(pv.x, 8, 64));           // the window's other y row
+                pv.y = fmaxf(pv.y, __shfl_xor(pv.y, 8, 64));
+                pv.z = fmaxf(pv.z, __shfl_xor(pv.z, 8, 64));
+                pv.w = fmaxf(pv.w, __shfl_xor(pv.w, 8, 64));
+                if (cok && eh == 0) {
+                    const int Dp = a.D / 2, Hp = a.H / 2, Wp = a.W / 2;
+                    *reinterpret_cast<float4*>(a.pool_out + ((((size_t)tile * Dp + oz0 / 2) * Hp + oy / 2) * Wp + ox / 2) * a.Cout + co) = pv;
                 }
             }
         }
