@@ -226,3 +226,18 @@ def test_no_packed_fp32_valu_and_hot_kernels_are_mfma(tmp_path):
         made = [ln.strip() for i0, i1 in zip(mf_i, mf_i[1:]) if i1 - i0 <= 60 for ln in body[i0:i1]
                 if re.search(r"\b(scratch_load|buffer_load|global_load_(?!dwordx4|lds_dwordx4))", ln)]
         assert not made, f"{sym}: compiler-made vector-memory loads inside a counted tap stream: {made[:3]}"
+    # (i) round 6: conv3_wino_f32 (the exact-fp32 path's k3 kernel).  Its chunk loop leans on the COMPILER's counted waits: every thread issues a fixed
+    # number of global loads per chunk (zero padding reads 16 zero bytes instead of skipping the load), so that the weight ring's waits stay
+    # `vmcnt(N > 0)` -- with a load under a branch the compiler falls back to full waits and the inputs' latency lands in front of tap 0
+    # (profiles/r06_wino_f32.md).  Per instantiation: 9 taps x 16 MFMAs, one barrier per chunk, no full wait and no scratch traffic in the loop.
+    for shape in ("ILi8ELi4E", "ILi16ELi2E", "ILi4ELi8E"):
+        sym = "_ZN3oai14conv3_wino_f32" + shape + "EEvNS_8ConvArgsEPKf"
+        m = re.search(r"^[0-9a-f]+ <" + sym + r">:\n(.*?)(?=^[0-9a-f]+ <)", text, flags=re.S | re.M)
+        assert m, f"{sym} not in the library"
+        body = [ln.split("//")[0] for ln in m.group(1).split("\n")]
+        mf_i = [i for i, ln in enumerate(body) if "v_mfma_f32_32x32x2_f32" in ln]
+        assert len(mf_i) == 144, (sym, len(mf_i))
+        loop = body[mf_i[0]:mf_i[-1] + 1]
+        assert not [ln for ln in body if "scratch_" in ln], f"{sym}: scratch traffic"
+        assert not [ln for ln in loop if "s_waitcnt" in ln and "vmcnt(0)" in ln], f"{sym}: a full vmcnt wait inside the chunk loop"
+        assert len([ln for ln in loop if "s_barrier" in ln]) == 1, f"{sym}: more than one barrier per chunk"
