@@ -77,3 +77,16 @@ def test_fulltile_golden_matches_oracle(golden_dir):
     y = oseg.unet_forward(torch.from_numpy(vol)[None, None], sd)[0].numpy()
     ref = z["logits_centre"]
     np.testing.assert_allclose(y[:, 8:24, 16:112, 16:112], ref, rtol=0, atol=2e-5 * float(z["logits_abs_max"]))
+
+
+def test_winograd_x_f32_emulation():
+    """The numerics argument behind conv3_wino_f32 (the exact-fp32 path's default since round 6), as arithmetic on the CPU: one layer's sums emulated in float32
+    in the kernels' orders (scripts/study/winograd_x_f32_error.py).  The x axis in Winograd F(2,3) form with a fresh partial sum per 8-channel chunk is no farther
+    from float64 than the direct two-level form, and both are several times closer than one running sum (what a plain fp32 convolution computes)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("winograd_x_f32_error", os.path.join(root, "scripts", "study", "winograd_x_f32_error.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    chain, two, wino = mod.errors(64, X=2048)
+    assert wino <= 1.05 * two and two < 0.6 * chain, (chain, two, wino)
