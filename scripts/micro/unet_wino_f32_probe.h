@@ -51,6 +51,14 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a,
     const int bz = id % a.nbz; id /= a.nbz;
     const int tile = id;
     const int oz0 = a.lo[0] + bz * TZ, oy0 = a.lo[1] + by * TY, ox0 = a.lo[2] + bx * TX;      // a.lo[2] is even (host)
+    // EXP 256 / 512: stagger the FIRST generation of workgroups (two share a CU and, equally long, would otherwise enter prologue and epilogue together):
+    // 256 = a pseudo-random delay of 0..17 x 8 128 cycles, 512 = the second 256 workgroups wait half a block time
+    if constexpr ((EXP & 256) != 0) {
+        if (blockIdx.x < 512u) { const unsigned n = ((blockIdx.x * 2654435761u) >> 16) % 18u; for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127); }
+    }
+    if constexpr ((EXP & 512) != 0) {
+        if (blockIdx.x >= 256u && blockIdx.x < 512u) { for (unsigned i = 0; i < 9; ++i) __builtin_amdgcn_s_sleep(127); }
+    }
     int blo[3], bhi[3];
     if (!tile_box(a.boxes, tile, a.lo, a.hi, blo, bhi)) return;
     if (oz0 >= bhi[0] || oz0 + TZ <= blo[0] || oy0 >= bhi[1] || oy0 + TY <= blo[1] || ox0 >= bhi[2] || ox0 + TX <= blo[2]) return;

@@ -88,6 +88,9 @@ int main() {
     RUNW(96, "  EXP 32+64");
     RUNW(128, "  EXP 128: full-line input fetches, once per 4 chunks");
     RUNW(160, "  EXP 128+32");
+    RUNW(256, "  EXP 256: first generation staggered (random)");
+    RUNW(512, "  EXP 512: first generation staggered (slot 1 waits)");
+    RUNW(256 + 31, "  EXP 256 + 1+2+4+8+16");
     RUNW(6, "  EXP 2+4");
     RUNW(22, "  EXP 2+4+16");
     RUNW(30, "  EXP 2+4+8+16");
