@@ -10,16 +10,18 @@
 //     out[X] = (m0 + m1) + m2       out[X + 1] = (m1 - m2) - m3
 // Products are exact fp32 x fp32 -> fp32 MFMA products as in conv3_igemm_f32, and the accumulation is the same TWO-LEVEL scheme: the 36 MFMAs of one
 // 8-channel chunk (9 taps x 4 k-steps) run into a fresh partial sum that is folded into the running sum by one add.  Emulated against float64
-// (scripts/study/winograd_x_f32_error.py: one layer, K = 576 ... 6 912): rms error 0.93-0.99 x the shipped two-level direct form's -- the shorter chains
+// (scripts/study/winograd_x_f32_error.py: one layer, K = 576 ... 6 912): rms error 0.87-0.97 x the two-level direct form's -- the shorter chains
 // pay for the transform's roundings.
 //
 // Workgroup = four waves = the four frequencies; block = 2 z x TY y x 2 NP x outputs (TY x NP = 32 pair rows = the M of the 32x32 MFMA tile per slice)
 // x 64 couts; wave f holds m_f for the whole block: 2 slices x 2 cout halves x 16 registers = 64 accumulators + 64 for the partial sums, the register
-// shape of conv3_igemm_f32.  Per chunk: [halo registers -> raw box (LDS)] [barrier] [transform raw -> T, one (hz, hy, pair, channel quad) unit per
-// thread] [barrier] [next chunk's halo loads issued] [9 taps: A fragments from T, weight fragments from L2 one tap ahead].  Epilogue: the four
-// frequencies of an output sit in four waves: every wave writes its 64 accumulators to LDS (64 KB, the raw box and T are dead), wave w then finalises
-// rows 8 w .. 8 w + 7 of every tile: output transform, scale / shift / ReLU, fp32 channels-last stores (32 consecutive couts = 128 bytes per lane row).
+// shape of conv3_igemm_f32.  ONE barrier per chunk: T is double-buffered; the next chunk's inputs are requested at tap 0 straight from global memory (a
+// thread = one (hz, hy, pair, channel quad) unit: its four x neighbours), transformed between the MFMA pairs of tap 5 into the other T buffer; A fragments
+// from T one tap ahead, weight fragments from L2 through a ring of three taps.  Epilogue: the four frequencies of an output sit in four waves: every
+// wave writes its 64 accumulators to LDS (64 KB, both T buffers are dead), wave w then finalises rows 8 w .. 8 w + 7 of every tile, a lane four
+// consecutive couts: output transform, scale / shift / ReLU, 16-byte channels-last stores, the fused MaxPool3d(2) of ec1 / ec3 / ec5.
 // An output's bits depend on the parity of its x only (pairs start at even tile coordinates: the host aligns the launch box) -- not on blocks or batches.
+// Measurements, the ablation probe and what is left: profiles/r06_wino_f32.md.
 #pragma once
 #include "unet_kernels.h"
 
