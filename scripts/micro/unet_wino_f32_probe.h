@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a,
     // other T buffer (two MFMAs, then the four VALU ops and the one LDS write of one frequency of one unit: the transform rides in the MFMAs' shadow).
     constexpr int kTapX = 5;
     static_assert(NU * 4 <= 8, "the pieces of a thread's units fit between the MFMA pairs of one tap");
+    if constexpr ((EXP & 1024) != 0) __builtin_amdgcn_s_setprio(3);      // EXP 1024: the chunk loop at high wave priority, prologue / epilogue at 0
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* const Tc = lds + (ch & 1) * TF + a_off;
         float* const Tn = lds + ((ch + 1) & 1) * TF;
@@ -227,6 +228,7 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a,
         if constexpr (!(EXP & 8)) __syncthreads();           // T[next] is written, T[this] is read by every wave
     }
 
+    if constexpr ((EXP & 1024) != 0) __builtin_amdgcn_s_setprio(0);
     // ---- epilogue: exchange the frequencies through LDS, output transform, scale / shift / ReLU, stores
     __syncthreads();
     float* const XB = lds;

@@ -91,6 +91,7 @@ int main() {
     RUNW(256, "  EXP 256: first generation staggered (random)");
     RUNW(512, "  EXP 512: first generation staggered (slot 1 waits)");
     RUNW(256 + 31, "  EXP 256 + 1+2+4+8+16");
+    RUNW(1024, "  EXP 1024: chunk loop at wave priority 3");
     RUNW(6, "  EXP 2+4");
     RUNW(22, "  EXP 2+4+16");
     RUNW(30, "  EXP 2+4+8+16");
