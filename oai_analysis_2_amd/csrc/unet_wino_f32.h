@@ -199,6 +199,15 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
     }
 
     // ---- epilogue: exchange the frequencies through LDS, output transform, scale / shift / ReLU, stores
+    // (a lane's epilogue role: four consecutive couts of one (j, half) -- see below; its scale / shift quads are requested here, in front of the exchange)
+    const int cq = lane & 7, eh = (lane >> 3) & 1, ej = lane >> 4;
+    float4 scq[NREP], shq[NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+        const int co = min(cb * 64 + n * 32 + 4 * cq, a.Cout - 4);      // (couts behind the last one are computed and never stored: any valid quad will do)
+        scq[n] = *reinterpret_cast<const float4*>(a.scale + co);
+        shq[n] = *reinterpret_cast<const float4*>(a.shift + co);
+    }
     __syncthreads();
     float* const XB = lds;
 #pragma unroll
@@ -213,7 +222,6 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
     // 16-byte stores (eight store instructions per wave instead of 64; Cout % 4 == 0: host).  For TY x NP = 8 x 4 the pair row is y = 2 w + half, pair j: the lane holds
     // both z slices and both x of a 2 x 2 x 2 pooling window, its partner lane ^ 8 the other y row -- the fused MaxPool3d(2) (ec1 / ec3 / ec5, networks.py:113,117,122;
     // the host passes pool_out only where the box is whole blocks) is one cross-lane max.
-    const int cq = lane & 7, eh = (lane >> 3) & 1, ej = lane >> 4;
     const int pr = ej + 8 * f + 4 * eh;
     const int oy = oy0 + pr / NP, ox = ox0 + 2 * (pr % NP);
     const bool yok = oy >= blo[1] && oy < bhi[1], x0ok = ox >= blo[2] && ox < bhi[2], x1ok = ox + 1 >= blo[2] && ox + 1 < bhi[2];
@@ -221,9 +229,7 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32(const ConvArgs a, const
     for (int n = 0; n < NREP; ++n) {
         const int co = cb * 64 + n * 32 + 4 * cq;
         const bool cok = co < a.Cout;
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 sc = cok ? *reinterpret_cast<const float4*>(a.scale + co) : zero4, sh = cok ? *reinterpret_cast<const float4*>(a.shift + co) : zero4;
-        asm volatile("" : "+v"(sc.x), "+v"(sc.y), "+v"(sc.z), "+v"(sc.w), "+v"(sh.x), "+v"(sh.y), "+v"(sh.z), "+v"(sh.w));      // (the wait for the loads lands here, once)
+        const float4 sc = scq[n], sh = shq[n];
         float4 pv = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {

@@ -155,11 +155,13 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a,
 #pragma unroll
         for (int n = 0; n < NREP; ++n) bq[i][n] = wp[(i * NREP + n) * 64];
     wp += 2 * NREP * 64;
+    if constexpr ((EXP & 4096) == 0) {        // EXP 4096: no first-chunk loads / transform in the prologue
     unit_load(0, true);
 #pragma unroll
     for (int ui = 0; ui < NU; ++ui)
 #pragma unroll
         for (int fq = 0; fq < 4; ++fq) unit_piece(lds, ui, fq);
+    }
     __syncthreads();
 
     // One barrier per chunk: the next chunk's inputs are requested at the head of this chunk's taps (straight from global memory: every unit reads its own
@@ -229,6 +231,17 @@ __global__ void __launch_bounds__(256, 2) conv3_wino_f32_probe(const ConvArgs a,
     }
 
     if constexpr ((EXP & 1024) != 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr ((EXP & 2048) != 0) {        // EXP 2048: no epilogue (one impossible store keeps the accumulators alive)
+        float sum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[m][n][r];
+        if (sum == 123.456f) a.out[tid] = sum;
+        return;
+    }
     // ---- epilogue: exchange the frequencies through LDS, output transform, scale / shift / ReLU, stores
     __syncthreads();
     float* const XB = lds;

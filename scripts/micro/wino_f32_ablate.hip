@@ -96,6 +96,10 @@ int main() {
     RUNW(22, "  EXP 2+4+16");
     RUNW(30, "  EXP 2+4+8+16");
     RUNW(31, "  EXP 1+2+4+8+16 (MFMAs + epilogue only)");
+    RUNW(31 + 2048, "  ... without the epilogue");
+    RUNW(31 + 4096, "  ... without the first chunk's loads and transform");
+    RUNW(31 + 2048 + 4096, "  ... without both");
+    RUNW(2048, "  EXP 2048: the full kernel without its epilogue");
     // direct: blocks of 2 x 8 x 16, (8 chunks x 27 taps x 4 k-steps x 4 accumulators) per wave
     a.wpanel = panel_d; a.nbz = D / 2; a.nby = H / 8; a.nbx = W / 16;
     const unsigned gd = (unsigned)tiles * a.nbz * a.nby * a.nbx;
